@@ -1,0 +1,166 @@
+/*
+ * mllp_hip.h -- C ABI of libmllp_hip.so: the MI355X (gfx950) implementation of mllp's learned-LP
+ * hot path (bipartite TransformerConv message passing over the LP constraint matrix, forward and
+ * backward, fused BCE head, flat Adam).
+ *
+ * The reference (HAHHHD/mllp) has no FFI/plugin interface: it is pure Python on PyTorch +
+ * PyTorch-Geometric.  The boundary a maintainer binds is therefore this
+ * header, loaded with ctypes from the Python modules that keep the reference's names
+ * (INTEGRATION.md shows the stub).  Each entry point cites the reference lines it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MLLP_E* code on failure;
+ *     mllp_last_error() returns a thread-local message for the last failure on this thread.
+ *   - "device pointer" arguments are caller-owned HIP device memory (e.g. torch tensors); the
+ *     library never frees or reallocates them and allocates nothing after mllp_graph_create_*.
+ *   - every launch is asynchronous on the hipStream_t passed as `stream` (void*; NULL = default
+ *     stream); no entry point synchronises except mllp_graph_create_* / mllp_graph_export.
+ *   - all launch functions are hipGraph-capturable (no malloc/free/sync inside).
+ *   - a mllp_graph_t is immutable after creation; it may be used from several streams.
+ *   - feature width is fixed at 16 (reference linear_program_methods.py:206-211), fp32 everywhere.
+ *   - there is NO CPU fallback: without a HIP device every launch function fails with MLLP_EHIP.
+ */
+#ifndef MLLP_HIP_H
+#define MLLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLLP_ABI_VERSION 1
+#define MLLP_FEAT 16
+#define MLLP_NUM_PARAMS 4721 /* GNNModel.state_dict(), SURVEY.md appendix A.2 */
+
+#define MLLP_OK 0
+#define MLLP_EINVAL (-1) /* bad argument (null pointer, shape mismatch, unsorted indices, ...) */
+#define MLLP_EHIP (-2)   /* a HIP runtime call failed (message has hipGetErrorString) */
+#define MLLP_ENOMEM (-3)
+#define MLLP_ERANGE (-4) /* sizes exceed int32 indexing */
+
+typedef struct mllp_graph mllp_graph_t;
+
+const char* mllp_last_error(void);
+int mllp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph: a block-diagonal batch of LP constraint matrices, resident in HBM in both orientations.
+ * Replaces the per-step Python graph build `build_graph_from_weights_sets`
+ * (linear_program_methods.py:89-103) and the batching rule `BipartiteData.__inc__`
+ * (linear_program_methods.py:60-72): variable ids of instance k are offset by sum_{j<k} n_j,
+ * constraint ids by sum_{j<k} m_j.  Built ONCE; the reference rebuilds it every step
+ * (linear_program_experiment.py:124).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* From host CSR pieces exactly as the reference loader returns them
+ * (linear_program_data.py:75-77: scipy CSR indptr/indices/data per instance).
+ *   indptr  : concatenation over instances of (m_k + 1) LOCAL row offsets (each block starts at 0)
+ *   indices : concatenation of LOCAL column ids (row-major, sorted within a row, no duplicates)
+ *   values  : float64 entries a_ij (cast to fp32 as linear_program_methods.py:100 does)
+ *   tier_wave, tier_block : rows with more than tier_wave nonzeros are processed by one 64-lane
+ *     wavefront, more than tier_block by one 256-thread workgroup; 0 = choose automatically.   */
+int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, const int64_t* inst_n,
+                           const int64_t* indptr, const int32_t* indices, const double* values,
+                           int32_t tier_wave, int32_t tier_block, mllp_graph_t** out);
+
+/* From device arrays that already hold the batch in global ids, both orientations (CSR of A:
+ * rows = constraints; CSR of A^T: rows = variables, row ids ascending within a column).  The
+ * arrays are copied.  inst_ptr_m / inst_ptr_n are HOST arrays of n_inst + 1 offsets.           */
+int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_m, const int64_t* inst_ptr_n,
+                             int64_t nnz,
+                             const int32_t* d_csr_ptr, const int32_t* d_csr_idx, const float* d_csr_val,
+                             const int32_t* d_csc_ptr, const int32_t* d_csc_idx, const float* d_csc_val,
+                             int32_t tier_wave, int32_t tier_block, void* stream, mllp_graph_t** out);
+
+int mllp_graph_destroy(mllp_graph_t* g);
+
+/* dims[0..9] = M (constraints), N (variables), nnz, n_inst,
+ *              rows in tier group/wave/block for A (dst = constraints),
+ *              rows in tier group/wave/block for A^T (dst = variables)                         */
+int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[10]);
+
+/* Copy one device array of the graph back to host memory (synchronises; tests/debugging).
+ * which: 0 csr_ptr(int32,M+1) 1 csr_idx(int32,nnz) 2 csr_val(f32,nnz)
+ *        3 csc_ptr(int32,N+1) 4 csc_idx(int32,nnz) 5 csc_val(f32,nnz) 6 inv_n(f32,N)            */
+int mllp_graph_export(const mllp_graph_t* g, int which, void* host_dst, int64_t capacity_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plain CSR SpMM (the roofline kernel named in BASELINE.json's metric):
+ *   transpose == 0:  Y[M,16] = A   * H[N,16]       transpose == 1:  Y[N,16] = A^T * H[M,16]
+ * This is the unweighted skeleton of the message passing in linear_program_methods.py:241-247
+ * (gather source rows by edge, scale by a_ij, add into the destination row).
+ * ---------------------------------------------------------------------------------------------- */
+int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One torch_geometric.nn.TransformerConv((cin, cin), 16, edge_dim=1) followed by ReLU, as called at
+ * linear_program_methods.py:241-247 (construction :206-211).  dst_is_var = 1 for the *_w2s convs
+ * (source = constraints, destination = variables), 0 for *_s2w.
+ *   d_conv_params : the conv's 9 tensors, flat, in state_dict order (lin_key.weight, lin_key.bias,
+ *                   lin_query.weight, lin_query.bias, lin_value.weight, lin_value.bias,
+ *                   lin_edge.weight, lin_skip.weight, lin_skip.bias): 144 floats (cin=1) or 1104.
+ *   d_x_src [N_src, cin], d_x_dst [N_dst, cin], d_h_out [N_dst, 16] = relu(conv(...))
+ *   d_ws : mllp_tconv_workspace_floats() floats; holds what backward needs (kept by the caller
+ *          between forward and backward).
+ * Backward: d_dh [N_dst,16] = dL/dh_out (overwritten with the ReLU-masked gradient);
+ *   d_dx_dst [N_dst,cin], d_dx_src [N_src,cin] may be NULL (then not computed; cin = 1 inputs are
+ *   data, linear_program_methods.py:90-91); accumulate bit 0 / bit 1 = add into d_dx_dst / d_dx_src
+ *   instead of overwriting; d_param_grads: same layout as d_conv_params (overwritten).
+ * ---------------------------------------------------------------------------------------------- */
+int mllp_tconv_workspace_floats(const mllp_graph_t* g, int dst_is_var, int cin, int64_t* n_floats);
+int mllp_tconv_fwd(const mllp_graph_t* g, int dst_is_var, int cin, const float* d_conv_params,
+                   const float* d_x_src, const float* d_x_dst, float* d_h_out, float* d_ws, void* stream);
+int mllp_tconv_bwd(const mllp_graph_t* g, int dst_is_var, int cin, const float* d_conv_params,
+                   const float* d_x_src, const float* d_x_dst, const float* d_h_out, float* d_ws,
+                   float* d_dh, float* d_dx_dst, float* d_dx_src, int accumulate,
+                   float* d_param_grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole model: GNNModel.forward (linear_program_methods.py:238-251) and its backward
+ * (autograd in the reference: linear_program_experiment.py:141).
+ *   d_params : MLLP_NUM_PARAMS floats, GNNModel.state_dict() order
+ *   d_x1 [N] = objective coefficients (x1, methods.py:90), d_x2 [M] = right-hand sides (x2, :91)
+ *   d_ws     : mllp_gnn_workspace_bytes() bytes, kept between forward and backward
+ *   d_logits [N] : per-variable logits (methods.py:250-251)
+ * mllp_gnn_backward: d_dlogits [N] -> d_grads [MLLP_NUM_PARAMS] (overwritten; the never-called
+ *   gconv3_s2w block, methods.py:248, is written as zeros).
+ * mllp_gnn_loss_step: forward + BCEWithLogitsLoss + backward in one call, loss =
+ *   inv_batch * sum_k mean_i BCE(logit_i, label_i) over the instances k of this graph
+ *   (linear_program_experiment.py:41,139-141 with batch size 1 and inv_batch = 1).
+ *   d_labels [N] float 0/1; d_loss: 1 float.
+ * ---------------------------------------------------------------------------------------------- */
+int mllp_gnn_workspace_bytes(const mllp_graph_t* g, int64_t* bytes);
+int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                     void* d_ws, float* d_logits, void* stream);
+int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                      void* d_ws, const float* d_dlogits, float* d_grads, void* stream);
+int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                       const float* d_labels, float inv_batch, void* d_ws, float* d_logits,
+                       float* d_loss, float* d_grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8), no weight decay
+ * (linear_program_experiment.py:119,143-144) on flat buffers.
+ *   d_state: 4 floats on the device {step (as float, incremented by the kernel), lr, beta1, beta2};
+ *            eps is passed by value.  grad_scale multiplies the gradient first (data-parallel
+ *            averaging).  Parameters whose gradient is exactly 0 with zero moments do not move,
+ *            which reproduces torch skipping `grad is None` parameters (gconv3_s2w).
+ * ---------------------------------------------------------------------------------------------- */
+int mllp_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
+                   float* d_state, float eps, float grad_scale, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Prediction + metrics (linear_program_experiment.py:146-151): per instance k, mark the m_k largest
+ * logits, correct_k = |pred & basis|, f1_k = 2TP / (2TP + FP + FN).
+ *   d_out [n_inst, 2] = {correct_k, f1_k}.   d_scratch: mllp_metrics_scratch_bytes() bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int mllp_metrics_scratch_bytes(const mllp_graph_t* g, int64_t* bytes);
+int mllp_topm_metrics(const mllp_graph_t* g, const float* d_logits, const float* d_labels,
+                      void* d_scratch, float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLLP_HIP_H */

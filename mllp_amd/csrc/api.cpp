@@ -1,0 +1,225 @@
+// api.cpp -- extern "C" entry points: one TransformerConv layer, the whole GNNModel
+// (reference linear_program_methods.py:202-251), the fused loss step, Adam, metrics.
+#include <algorithm>
+
+#include "internal.h"
+
+namespace mllp {
+
+static inline int64_t up16(int64_t x) { return (x + 15) & ~int64_t(15); }
+
+int64_t conv_ws_floats(int64_t n, int cin) {
+    const int64_t recw = cin == 16 ? REC_W : 8;
+    return up16(DERIVED_W) + up16(n * cin) + up16(n) + up16(n * cin) + up16(n * 4) + up16(n * recw) + up16(n * cin) +
+           up16(n * 2) + up16((int64_t)STAT_BLOCKS_MAX * STAT_FLOATS);
+}
+
+ConvWs conv_ws_carve(float* base, int64_t n, int cin) {
+    const int64_t recw = cin == 16 ? REC_W : 8;
+    ConvWs w;
+    float* p = base;
+    w.derived = p; p += up16(DERIVED_W);
+    w.qp = p; p += up16(n * cin);
+    w.t = p; p += up16(n);
+    w.Z = p; p += up16(n * cin);
+    w.aux = p; p += up16(n * 4);
+    w.rec = p; p += up16(n * recw);
+    w.dqp = p; p += up16(n * cin);
+    w.dsdt = p; p += up16(n * 2);
+    w.stats = p;
+    return w;
+}
+
+static int conv_forward(const mllp_graph* g, bool dst_is_var, int cin, const float* cp, const ConvWs& w,
+                        const float* x_src, const float* x_dst, float* h_out, hipStream_t s) {
+    const Orient& o = dst_is_var ? g->At : g->A;
+    int rc;
+    if ((rc = launch_param_prep(cp, cin, w.derived, s))) return rc;
+    if (cin == 16 && (rc = launch_node_qp(x_dst, o.n_dst, w.derived, w.qp, w.t, s))) return rc;
+    return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, s);
+}
+
+// dh is overwritten with the ReLU-masked gradient; dx_* may be null; acc bit0 -> dx_dst, bit1 -> dx_src
+static int conv_backward(const mllp_graph* g, bool dst_is_var, int cin, const float* cp, const ConvWs& w,
+                         const float* x_src, const float* x_dst, const float* h_out, float* dh, float* dx_dst,
+                         float* dx_src, int acc, float* param_grads, hipStream_t s) {
+    const Orient& o = dst_is_var ? g->At : g->A;       // destination-major
+    const Orient& ot = dst_is_var ? g->A : g->At;      // source-major (rows = source nodes)
+    int rc;
+    if ((rc = launch_bwd_pre(o.n_dst, cin, cp, w, x_dst, h_out, dh, s))) return rc;
+    if ((rc = launch_attn_bwd_dst(o, cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, s))) return rc;
+    if (cin == 16 && dx_src && (rc = launch_attn_bwd_src(ot, w, x_src, dx_src, (acc >> 1) & 1, s))) return rc;
+    if ((rc = launch_param_stats(cin, o.n_dst, w, x_dst, dh, s))) return rc;
+    return launch_finalize_conv(cin, cp, w.stats, stat_blocks_for(o.n_dst), param_grads, s);
+}
+
+// ---- whole-model workspace ----------------------------------------------------------------------
+struct ModelWs {
+    ConvWs c1v, c1c, c2v, c2c, c3v;
+    float *h1v, *h1c, *h2v, *h2c, *h3v;
+    float *d3v, *d2v, *d2c, *d1v, *d1c;
+    float* head_partials;
+    int64_t total;
+};
+constexpr int HEAD_PART_FLOATS = 1024 * 18;
+
+static ModelWs model_ws(const mllp_graph* g, float* base) {
+    const int64_t N = g->N, M = g->M;
+    ModelWs w;
+    float* p = base;
+    auto conv = [&](int64_t n, int cin) {
+        ConvWs c = conv_ws_carve(p, n, cin);
+        p += conv_ws_floats(n, cin);
+        return c;
+    };
+    auto buf = [&](int64_t n) {
+        float* q = p;
+        p += up16(n);
+        return q;
+    };
+    w.c1v = conv(N, 1);
+    w.c1c = conv(M, 1);
+    w.c2v = conv(N, 16);
+    w.c2c = conv(M, 16);
+    w.c3v = conv(N, 16);
+    w.h1v = buf(N * 16); w.h1c = buf(M * 16);
+    w.h2v = buf(N * 16); w.h2c = buf(M * 16);
+    w.h3v = buf(N * 16);
+    w.d3v = buf(N * 16); w.d2v = buf(N * 16); w.d2c = buf(M * 16);
+    w.d1v = buf(N * 16); w.d1c = buf(M * 16);
+    w.head_partials = buf(HEAD_PART_FLOATS);
+    w.total = p - base;
+    return w;
+}
+
+// offsets of the convs in GNNModel.state_dict() order
+constexpr int OFF_C1V = 0, OFF_C1C = 144, OFF_C2V = 288, OFF_C2C = 1392, OFF_C3V = 2496, OFF_C3C = 3600, OFF_FC = 4704;
+
+static int model_forward_body(const mllp_graph* g, const float* P, const float* x1, const float* x2, const ModelWs& w,
+                              hipStream_t s) {
+    int rc;
+    // linear_program_methods.py:241-242  layer 1 (scalar inputs), both directions from the SAME inputs
+    if ((rc = conv_forward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, s))) return rc;
+    if ((rc = conv_forward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, s))) return rc;
+    // :244-245  layer 2 (simultaneous update: both read layer-1 outputs)
+    if ((rc = conv_forward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, s))) return rc;
+    if ((rc = conv_forward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, s))) return rc;
+    // :247  layer 3, variables only (gconv3_s2w is never called, :248)
+    return conv_forward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, s);
+}
+
+static int model_backward_body(const mllp_graph* g, const float* P, const float* x1, const float* x2,
+                               const ModelWs& w, float* grads, hipStream_t s) {
+    int rc;
+    if ((rc = conv_backward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, w.d3v, w.d2v, w.d2c, 0,
+                            grads + OFF_C3V, s))) return rc;
+    if ((rc = conv_backward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, w.d2v, w.d1v, w.d1c, 0,
+                            grads + OFF_C2V, s))) return rc;
+    if ((rc = conv_backward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, w.d2c, w.d1c, w.d1v, 3,
+                            grads + OFF_C2C, s))) return rc;
+    if ((rc = conv_backward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, w.d1v, nullptr, nullptr, 0,
+                            grads + OFF_C1V, s))) return rc;
+    if ((rc = conv_backward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, w.d1c, nullptr, nullptr, 0,
+                            grads + OFF_C1C, s))) return rc;
+    return launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, s);
+}
+
+}  // namespace mllp
+
+using namespace mllp;
+
+#define REQUIRE(cond, msg) \
+    if (!(cond)) return fail(MLLP_EINVAL, std::string(__func__) + ": " + (msg))
+
+extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream) {
+    REQUIRE(g && d_H && d_Y, "null argument");
+    return launch_spmm(transpose ? g->At : g->A, d_H, d_Y, (hipStream_t)stream);
+}
+
+extern "C" int mllp_tconv_workspace_floats(const mllp_graph_t* g, int dst_is_var, int cin, int64_t* n_floats) {
+    REQUIRE(g && n_floats, "null argument");
+    REQUIRE(cin == 1 || cin == 16, "cin must be 1 or 16");
+    *n_floats = conv_ws_floats(dst_is_var ? g->N : g->M, cin);
+    return MLLP_OK;
+}
+
+extern "C" int mllp_tconv_fwd(const mllp_graph_t* g, int dst_is_var, int cin, const float* d_conv_params,
+                              const float* d_x_src, const float* d_x_dst, float* d_h_out, float* d_ws, void* stream) {
+    REQUIRE(g && d_conv_params && d_x_src && d_x_dst && d_h_out && d_ws, "null argument");
+    REQUIRE(cin == 1 || cin == 16, "cin must be 1 or 16");
+    ConvWs w = conv_ws_carve(d_ws, dst_is_var ? g->N : g->M, cin);
+    return conv_forward(g, dst_is_var != 0, cin, d_conv_params, w, d_x_src, d_x_dst, d_h_out, (hipStream_t)stream);
+}
+
+extern "C" int mllp_tconv_bwd(const mllp_graph_t* g, int dst_is_var, int cin, const float* d_conv_params,
+                              const float* d_x_src, const float* d_x_dst, const float* d_h_out, float* d_ws,
+                              float* d_dh, float* d_dx_dst, float* d_dx_src, int accumulate, float* d_param_grads,
+                              void* stream) {
+    REQUIRE(g && d_conv_params && d_x_src && d_x_dst && d_h_out && d_ws && d_dh && d_param_grads, "null argument");
+    REQUIRE(cin == 1 || cin == 16, "cin must be 1 or 16");
+    ConvWs w = conv_ws_carve(d_ws, dst_is_var ? g->N : g->M, cin);
+    return conv_backward(g, dst_is_var != 0, cin, d_conv_params, w, d_x_src, d_x_dst, d_h_out, d_dh, d_dx_dst,
+                         d_dx_src, accumulate, d_param_grads, (hipStream_t)stream);
+}
+
+extern "C" int mllp_gnn_workspace_bytes(const mllp_graph_t* g, int64_t* bytes) {
+    REQUIRE(g && bytes, "null argument");
+    *bytes = model_ws(g, nullptr).total * (int64_t)sizeof(float);
+    return MLLP_OK;
+}
+
+extern "C" int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                                void* d_ws, float* d_logits, void* stream) {
+    REQUIRE(g && d_params && d_x1 && d_x2 && d_ws && d_logits, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ModelWs w = model_ws(g, (float*)d_ws);
+    int rc;
+    if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
+    return launch_head(0, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f, nullptr,
+                       d_logits, nullptr, w.head_partials, s);
+}
+
+extern "C" int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                                 void* d_ws, const float* d_dlogits, float* d_grads, void* stream) {
+    REQUIRE(g && d_params && d_x1 && d_x2 && d_ws && d_dlogits && d_grads, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ModelWs w = model_ws(g, (float*)d_ws);
+    int rc;
+    if ((rc = launch_head(1, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f,
+                          d_dlogits, nullptr, w.d3v, w.head_partials, s))) return rc;
+    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, s))) return rc;
+    return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
+}
+
+extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, const float* d_x1, const float* d_x2,
+                                  const float* d_labels, float inv_batch, void* d_ws, float* d_logits, float* d_loss,
+                                  float* d_grads, void* stream) {
+    REQUIRE(g && d_params && d_x1 && d_x2 && d_labels && d_ws && d_logits && d_loss && d_grads, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ModelWs w = model_ws(g, (float*)d_ws);
+    int rc;
+    if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
+    if ((rc = launch_head(2, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, d_labels, inv_batch,
+                          nullptr, d_logits, w.d3v, w.head_partials, s))) return rc;
+    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, d_loss, s))) return rc;
+    return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
+}
+
+extern "C" int mllp_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
+                              float* d_state, float eps, float grad_scale, int64_t n, void* stream) {
+    REQUIRE(d_params && d_grads && d_exp_avg && d_exp_avg_sq && d_state, "null argument");
+    REQUIRE(n > 0 && n < (int64_t)1 << 30, "bad parameter count");
+    return launch_adam(d_params, d_grads, d_exp_avg, d_exp_avg_sq, d_state, eps, grad_scale, n, (hipStream_t)stream);
+}
+
+extern "C" int mllp_metrics_scratch_bytes(const mllp_graph_t* g, int64_t* bytes) {
+    REQUIRE(g && bytes, "null argument");
+    *bytes = 16;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_topm_metrics(const mllp_graph_t* g, const float* d_logits, const float* d_labels, void* d_scratch,
+                                 float* d_out, void* stream) {
+    REQUIRE(g && d_logits && d_labels && d_out, "null argument");
+    return launch_topm_metrics(g, d_logits, d_labels, d_scratch, d_out, (hipStream_t)stream);
+}

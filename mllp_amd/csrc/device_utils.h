@@ -1,0 +1,106 @@
+// device_utils.h -- gfx950 device helpers: DPP cross-lane reductions inside 16-lane rows and
+// 64-lane wavefronts, XCD-aware tile remap, small vector helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mllp {
+
+constexpr float NEG_BIG = -3.0e38f;  // "minus infinity" sentinel that never produces inf - inf
+
+// ---- DPP (data-parallel primitives): lane permutations inside a row of 16 lanes ------------------
+// dpp_ctrl encodings (CDNA ISA): quad_perm = 0x00..0xFF, row_mirror = 0x140, row_half_mirror = 0x141
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce over the 16 lanes of a DPP row (every lane ends with the result)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2] : lane ^ 1
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1] : lane ^ 2
+    v += dpp_mov<0x141>(v);  // row_half_mirror     : quad 0 <-> quad 1 inside each 8
+    v += dpp_mov<0x140>(v);  // row_mirror          : half 0 <-> half 1 inside the 16
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+// G = 16: one DPP row.  G = 64: the whole wavefront (two more butterfly steps through the LDS crossbar).
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
+    if (G == 64) {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    v = row16_max(v);
+    if (G == 64) {
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+    }
+    return v;
+}
+
+// value v[c] for a lane-dependent c in [0,16): 15 v_cndmask.  The operands are copied to prvalues first:
+// `cond ? v[a] : v[b]` on lvalues makes clang select the ADDRESS, which turns the register array into a
+// dynamically indexed alloca (scratch / LDS-promoted) -- measured: 16 KB of LDS per workgroup.
+__device__ __forceinline__ float select16(const float (&v)[16], int c) {
+    float a[8], b[4], d[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float hi = v[2 * i + 1], lo = v[2 * i];
+        a[i] = (c & 1) ? hi : lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float hi = a[2 * i + 1], lo = a[2 * i];
+        b[i] = (c & 2) ? hi : lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float hi = b[2 * i + 1], lo = b[2 * i];
+        d[i] = (c & 4) ? hi : lo;
+    }
+    const float hi = d[1], lo = d[0];
+    return (c & 8) ? hi : lo;
+}
+
+__device__ __forceinline__ void load_row16(const float* __restrict__ p, float (&r)[16]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 t = q[i];
+        r[4 * i + 0] = t.x;
+        r[4 * i + 1] = t.y;
+        r[4 * i + 2] = t.z;
+        r[4 * i + 3] = t.w;
+    }
+}
+
+__device__ __forceinline__ float dot16(const float (&a)[16], const float (&b)[16], float init) {
+    float s = init;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = fmaf(a[i], b[i], s);
+    return s;
+}
+
+// XCD-aware, bijective block -> tile remap (guide T1): blocks b and b+8 share an XCD (and its L2),
+// so give each XCD a contiguous range of tiles; consecutive tiles then gather the same source rows
+// from one L2.  Valid for any number of tiles.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+    int q = n >> 3, r = n & 7, x = b & 7;
+    int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (b >> 3);
+}
+
+}  // namespace mllp

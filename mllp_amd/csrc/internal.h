@@ -1,0 +1,138 @@
+// internal.h -- shared declarations of libmllp_hip.so (not part of the public ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mllp_hip.h"
+
+namespace mllp {
+
+constexpr int FEAT = 16;
+constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
+constexpr int REC_W = 40;      // floats per destination record read by the source-major backward sweep
+constexpr int STAT_TILES = 7;  // 16x16 outer-product tiles reduced over nodes per conv
+constexpr int STAT_FLOATS = STAT_TILES * 256;
+constexpr int STAT_BLOCKS_MAX = 256;
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define MLLP_HIP_TRY(expr)                                              \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if (_e != hipSuccess) return ::mllp::hip_fail(_e, #expr);       \
+    } while (0)
+
+// One traversal orientation: destination-major CSR over the sparsity pattern of A (dst = constraint
+// rows) or of A^T (dst = variable columns).  Rows are split in three tiers by nonzero count:
+//   group tier: 16 lanes per row (4 rows per wavefront), wave tier: 64 lanes per row,
+//   block tier: one 256-thread workgroup per row.
+struct Orient {
+    int n_dst = 0, n_src = 0;
+    int* ptr = nullptr;    // [n_dst + 1]
+    int* idx = nullptr;    // [nnz] source ids
+    float* val = nullptr;  // [nnz] a_ij
+    int* rows_group = nullptr;  // nullptr => identity (every row is in the group tier)
+    int* rows_wave = nullptr;
+    int* rows_block = nullptr;
+    int n_group = 0, n_wave = 0, n_block = 0;
+};
+
+}  // namespace mllp
+
+struct mllp_graph {
+    int64_t M = 0, N = 0, nnz = 0, n_inst = 0;
+    mllp::Orient A;   // dst = constraints, src = variables
+    mllp::Orient At;  // dst = variables,   src = constraints
+    float* inv_n = nullptr;      // [N] 1 / n_k of the owning instance
+    int* inst_ptr_n = nullptr;   // [n_inst + 1] device
+    int* inst_ptr_m = nullptr;   // [n_inst + 1] device
+    std::vector<int64_t> h_inst_ptr_n, h_inst_ptr_m;
+    int tier_wave = 0, tier_block = 0;
+    int max_inst_n = 0;
+    std::vector<void*> allocs;   // everything to hipFree on destroy
+};
+
+namespace mllp {
+
+// ---- per-conv parameter views into the flat state_dict-ordered buffer ---------------------------
+struct ConvParams {
+    const float *Wk, *bk, *Wq, *bq, *Wv, *bv, *we, *Ws, *bs;
+};
+inline int conv_param_count(int cin) { return 4 * FEAT * cin + 5 * FEAT; }
+inline ConvParams conv_params_at(const float* base, int cin) {
+    ConvParams p;
+    const float* q = base;
+    p.Wk = q; q += FEAT * cin;
+    p.bk = q; q += FEAT;
+    p.Wq = q; q += FEAT * cin;
+    p.bq = q; q += FEAT;
+    p.Wv = q; q += FEAT * cin;
+    p.bv = q; q += FEAT;
+    p.we = q; q += FEAT;
+    p.Ws = q; q += FEAT * cin;
+    p.bs = q;
+    return p;
+}
+
+// folded weights written by the param_prep kernel (per conv; DERIVED_W floats, same layout for cin 1/16)
+//   Pq [k][d]  = sum_c Wk[c][k] Wq[c][d] / 4      q'_i = Pq x_i + pq0   (logit scale 1/sqrt(16) folded in)
+//   PqT[d][k]  = Pq[k][d]
+//   WsT[d][o]  = Ws[o][d]          WvT[k][o] = Wv[o][k]
+//   pq0[k]     = sum_c Wk[c][k] bq[c] / 4
+//   Pt [d]     = sum_c we[c] Wq[c][d] / 4 ,  pt0 = <bq, we> / 4        t_i = <Pt, x_i> + pt0
+//   Pb [d]     = sum_c bk[c] Wq[c][d] / 4                              (backward only)
+constexpr int OFF_PQ = 0, OFF_PQT = 256, OFF_WST = 512, OFF_WVT = 768;
+constexpr int OFF_PQ0 = 1024, OFF_PT = 1040, OFF_PB = 1056, OFF_PT0 = 1072;
+constexpr int DERIVED_W = 1088;
+
+// workspace of one conv (floats): what forward saves for backward + backward scratch
+struct ConvWs {
+    float* derived;  // [DERIVED_W]
+    float* qp;       // [n_dst, cin]
+    float* t;        // [n_dst]
+    float* Z;        // [n_dst, cin]   normalised attention-weighted source sum
+    float* aux;      // [n_dst, 4]     {u, rowmax, 1/(rowsum+1e-16), S}
+    float* rec;      // [n_dst, REC_W] backward record (cin = 16) / [n_dst, 8] (cin = 1)
+    float* dqp;      // [n_dst, cin]
+    float* dsdt;     // [n_dst, 2]
+    float* stats;    // [STAT_BLOCKS_MAX, STAT_FLOATS] per-workgroup partial statistics
+};
+int64_t conv_ws_floats(int64_t n_dst, int cin);
+ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
+
+// ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
+int launch_spmm(const Orient& o, const float* H, float* Y, hipStream_t s);
+int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s);
+int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s);
+int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
+                    const float* x_dst, float* h_out, hipStream_t s);
+int launch_bwd_pre(int64_t n_dst, int cin, const float* conv_params, const ConvWs& w, const float* x_dst,
+                   const float* h_out, float* dh, hipStream_t s);
+int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
+                        const float* g, float* dx_dst, int accumulate, hipStream_t s);
+int launch_attn_bwd_src(const Orient& o_src_major, const ConvWs& w, const float* x_src, float* dx_src,
+                        int accumulate, hipStream_t s);
+int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_dst, const float* g, hipStream_t s);
+int launch_finalize_conv(int cin, const float* conv_params, const float* stats, int n_stat_blocks, float* grads,
+                         hipStream_t s);
+int stat_blocks_for(int64_t n_dst);
+
+// head: mode 0 = logits only, 1 = backward from given dlogits, 2 = fused BCE forward+backward
+int launch_head(int mode, int64_t n, const float* h3v, const float* fc_w, const float* fc_b, const float* inv_n,
+                const float* labels, float inv_batch, const float* dlogits_in, float* logits, float* dh3v,
+                float* partials, hipStream_t s);
+int launch_head_finalize(const float* partials, int n_blocks, float* grad_fc /*17*/, float* loss /*nullable*/,
+                         hipStream_t s);
+int head_blocks_for(int64_t n);
+int launch_adam(float* p, const float* g, float* m, float* v, float* state, float eps, float gscale, int64_t n,
+                hipStream_t s);
+int launch_fill_zero(float* p, int64_t n, hipStream_t s);
+int launch_topm_metrics(const mllp_graph* g, const float* logits, const float* labels, void* scratch, float* out,
+                        hipStream_t s);
+
+}  // namespace mllp

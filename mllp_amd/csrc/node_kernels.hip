@@ -1,0 +1,586 @@
+// node_kernels.hip -- dense per-node work around the sparse sweeps (gfx950):
+//   param_prep      fold the conv weights once per step (q' = Wk^T q / 4 etc.)
+//   node_qp         Q' = X Pq^T + pq0, t = X Pt + pt0            (MFMA v_mfma_f32_16x16x4_f32, exact fp32)
+//   bwd_pre         ReLU mask, gv = Wv^T g, ge, c -> per-destination backward record
+//   param_stats     sum over nodes of the outer products that make up the parameter gradients
+//                   (MFMA 16x16x4 with K = nodes; deterministic two-stage reduction, no atomics)
+//   finalize_conv   partial statistics -> the conv's 9 gradient tensors
+//   head            fc (16 -> 1) + BCEWithLogits forward/backward, fused
+//   adam            torch.optim.Adam on the flat parameter buffer
+//   topm_metrics    per-instance top-m prediction, correct count and F1
+// Reference call sites: linear_program_methods.py:241-251 (layers, relu, fc),
+// linear_program_experiment.py:41,139-151 (loss, Adam, top-k metrics).
+#include "device_utils.h"
+#include "internal.h"
+
+namespace mllp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// -------------------------------------------------------------------------------------------------
+// param_prep: one workgroup per conv
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void param_prep_kernel(ConvParams p, int cin, float* __restrict__ D) {
+    const int tid = threadIdx.x;
+    const int k = tid >> 4, d = tid & 15;
+    float pq = 0.0f, wst = 0.0f, wvt = 0.0f;
+    if (k < cin && d < cin) {
+        for (int c = 0; c < 16; ++c) pq = fmaf(p.Wk[c * cin + k], p.Wq[c * cin + d], pq);
+        pq *= 0.25f;
+    }
+    if (k < cin) {            // here: k = input channel, d = output channel
+        wst = p.Ws[d * cin + k];
+        wvt = p.Wv[d * cin + k];
+    }
+    D[OFF_PQ + k * 16 + d] = pq;
+    D[OFF_PQT + d * 16 + k] = pq;
+    D[OFF_WST + k * 16 + d] = wst;
+    D[OFF_WVT + k * 16 + d] = wvt;
+    if (tid < 16) {
+        float pq0 = 0.0f, pt = 0.0f, pb = 0.0f;
+        if (tid < cin) {
+            for (int c = 0; c < 16; ++c) {
+                pq0 = fmaf(p.Wk[c * cin + tid], p.bq[c], pq0);
+                pt = fmaf(p.we[c], p.Wq[c * cin + tid], pt);
+                pb = fmaf(p.bk[c], p.Wq[c * cin + tid], pb);
+            }
+        }
+        float pt0 = 0.0f;
+        if (tid == 0)
+            for (int c = 0; c < 16; ++c) pt0 = fmaf(p.bq[c], p.we[c], pt0);
+        D[OFF_PQ0 + tid] = 0.25f * pq0;
+        D[OFF_PT + tid] = 0.25f * pt;
+        D[OFF_PB + tid] = 0.25f * pb;
+        D[OFF_PT0 + tid] = 0.25f * pt0;
+    }
+}
+
+int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s) {
+    hipLaunchKernelGGL(param_prep_kernel, dim3(1), dim3(BLOCK), 0, s, conv_params_at(conv_params, cin), cin, derived);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "param_prep");
+}
+
+// -------------------------------------------------------------------------------------------------
+// node_qp (cin = 16): one wavefront per 16 nodes, 4 MFMA 16x16x4 (K = 16 input channels)
+//   A[i = lane & 15][k = lane >> 4] = X[node0 + i][4 s + k]     B[k][j = lane & 15] = PqT[4 s + k][j]
+//   D[row = 4 (lane >> 4) + r][col = lane & 15]
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void node_qp_kernel(const float* __restrict__ X, int n, const float* __restrict__ D,
+                                                        float* __restrict__ qp, float* __restrict__ t) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int node0 = (blockIdx.x * 4 + wave) * 16;
+    if (node0 >= n) return;
+    const int r = lane & 15, kq = lane >> 4;
+    const bool ok = node0 + r < n;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float tpart = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int d = 4 * s + kq;
+        const float a = ok ? X[(size_t)(node0 + r) * 16 + d] : 0.0f;
+        const float b = D[OFF_PQT + d * 16 + r];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        tpart = fmaf(a, D[OFF_PT + d], tpart);
+    }
+    tpart += __shfl_xor(tpart, 16, 64);
+    tpart += __shfl_xor(tpart, 32, 64);
+    if (kq == 0 && ok) t[node0 + r] = tpart + D[OFF_PT0];
+    const float bias = D[OFF_PQ0 + r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int node = node0 + kq * 4 + j;
+        if (node < n) qp[(size_t)node * 16 + r] = acc[j] + bias;
+    }
+}
+
+int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s) {
+    if (n_dst == 0) return MLLP_OK;
+    const int64_t blocks = (n_dst + 63) / 64;
+    hipLaunchKernelGGL(node_qp_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, s, x_dst, (int)n_dst, derived, qp, t);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "node_qp");
+}
+
+// -------------------------------------------------------------------------------------------------
+// bwd_pre: 16 lanes per destination node.  g = dh * (h > 0) written back in place; record for the sweeps.
+// -------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(BLOCK) void bwd_pre_kernel(int n, ConvParams p, const float* __restrict__ D,
+                                                        const float* __restrict__ h, float* __restrict__ dh,
+                                                        const float* __restrict__ xd, const float* __restrict__ qp,
+                                                        const float* __restrict__ t, const float* __restrict__ Z,
+                                                        const float* __restrict__ aux, float* __restrict__ rec) {
+    const int node = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int k = threadIdx.x & 15;
+    if (node >= n) return;
+    const float hk = h[(size_t)node * 16 + k];
+    const float gk = hk > 0.0f ? dh[(size_t)node * 16 + k] : 0.0f;
+    float hr[16], gr[16];
+    if (CIN == 16) {   // every lane needs the whole masked g row (gv_k = sum_o g_o Wv[o][k]): read it before the store
+        load_row16(h + (size_t)node * 16, hr);
+        load_row16(dh + (size_t)node * 16, gr);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) gr[o] = hr[o] > 0.0f ? gr[o] : 0.0f;
+    }
+    dh[(size_t)node * 16 + k] = gk;
+    const float4 ax = reinterpret_cast<const float4*>(aux)[node];  // {u, rowmax, rinv, S}
+    const float ge = row16_sum(gk * p.we[k]);
+    const float gb = row16_sum(gk * p.bv[k]);
+    if (CIN == 16) {
+        float wvt[16];
+        load_row16(D + OFF_WVT + k * 16, wvt);
+        const float gv = dot16(wvt, gr, 0.0f);
+        const float Dn = row16_sum(gv * Z[(size_t)node * 16 + k]) + gb * ax.w + ge * ax.x;
+        const float cc = gb - Dn;
+        float* r = rec + (size_t)node * REC_W;
+        r[k] = qp[(size_t)node * 16 + k];
+        r[16 + k] = gv;
+        if (k < 8) {
+            const float tv = t[node];
+            float v = 0.0f;
+            v = k == 0 ? tv : v;
+            v = k == 1 ? ax.y : v;
+            v = k == 2 ? ax.z : v;
+            v = k == 3 ? ge : v;
+            v = k == 4 ? cc : v;
+            r[32 + k] = v;
+        }
+    } else {
+        const float gv = row16_sum(gk * p.Wv[k]);
+        const float Dn = gv * Z[node] + gb * ax.w + ge * ax.x;
+        const float cc = gb - Dn;
+        const float x = xd[node];
+        const float q1 = fmaf(D[OFF_PQ], x, D[OFF_PQ0]);
+        const float t1 = fmaf(D[OFF_PT], x, D[OFF_PT0]);
+        if (k < 8) {
+            float v = 0.0f;
+            v = k == 0 ? q1 : v;
+            v = k == 1 ? gv : v;
+            v = k == 2 ? t1 : v;
+            v = k == 3 ? ax.y : v;
+            v = k == 4 ? ax.z : v;
+            v = k == 5 ? ge : v;
+            v = k == 6 ? cc : v;
+            rec[(size_t)node * 8 + k] = v;
+        }
+    }
+}
+
+int launch_bwd_pre(int64_t n_dst, int cin, const float* conv_params, const ConvWs& w, const float* x_dst,
+                     const float* h_out, float* dh, hipStream_t s) {
+    if (n_dst == 0) return MLLP_OK;
+    const int64_t blocks = (n_dst + 15) / 16;
+    ConvParams p = conv_params_at(conv_params, cin);
+    if (cin == 16)
+        hipLaunchKernelGGL(bwd_pre_kernel<16>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, (int)n_dst, p, w.derived,
+                           h_out, dh, x_dst, w.qp, w.t, w.Z, w.aux, w.rec);
+    else
+        hipLaunchKernelGGL(bwd_pre_kernel<1>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, (int)n_dst, p, w.derived, h_out,
+                           dh, x_dst, w.qp, w.t, w.Z, w.aux, w.rec);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwd_pre");
+}
+
+// -------------------------------------------------------------------------------------------------
+// param_stats: T[p][q] = sum_nodes L_node[p] * R_node[q] for seven 16x16 tiles
+//   T0 g x^T   T1 g Z^T   T2 g e^T   T3 dq' x^T   T4 dq' e^T   T5 sc x^T   T6 sc e^T
+//   e = [1, S, u, 0...],  sc = [ds, dt, 0...]
+// cin = 16: MFMA with K = 4 nodes per instruction: A[p = lane & 15][kk = lane >> 4] = L[node0 + kk][p],
+//           B[kk][q = lane & 15] = R[node0 + kk][q]  -- both are plain coalesced dword loads.
+// -------------------------------------------------------------------------------------------------
+int stat_blocks_for(int64_t n_dst) {
+    int64_t b = (n_dst + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > STAT_BLOCKS_MAX) b = STAT_BLOCKS_MAX;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(BLOCK) void param_stats16_kernel(int n, const float* __restrict__ g,
+                                                              const float* __restrict__ x, const float* __restrict__ Z,
+                                                              const float* __restrict__ aux,
+                                                              const float* __restrict__ dqp,
+                                                              const float* __restrict__ dsdt, float* __restrict__ out) {
+    __shared__ float sh[4][STAT_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc[STAT_TILES];
+#pragma unroll
+    for (int i = 0; i < STAT_TILES; ++i) acc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int nchunk = (n + 3) >> 2;
+    for (int ch = blockIdx.x * 4 + wave; ch < nchunk; ch += gridDim.x * 4) {
+        const int node = ch * 4 + kq;
+        float ag = 0.0f, adq = 0.0f, asc = 0.0f, bx = 0.0f, bz = 0.0f, be = 0.0f;
+        if (node < n) {
+            ag = g[(size_t)node * 16 + r];
+            adq = dqp[(size_t)node * 16 + r];
+            bx = x[(size_t)node * 16 + r];
+            bz = Z[(size_t)node * 16 + r];
+            const float2 sd = reinterpret_cast<const float2*>(dsdt)[node];
+            const float4 ax = reinterpret_cast<const float4*>(aux)[node];
+            asc = r == 0 ? sd.x : (r == 1 ? sd.y : 0.0f);
+            be = r == 0 ? 1.0f : (r == 1 ? ax.w : (r == 2 ? ax.x : 0.0f));
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, bx, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, bz, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, be, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq, bx, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq, be, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc, bx, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc, be, acc[6], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < STAT_TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[wave][i * 256 + (kq * 4 + j) * 16 + r] = acc[i][j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK)
+        out[(size_t)blockIdx.x * STAT_FLOATS + i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+}
+
+// cin = 1: node features, Z, dq' are scalars; 16 lanes per node (lane o owns g_o); same tile layout out.
+__global__ __launch_bounds__(BLOCK) void param_stats1_kernel(int n, const float* __restrict__ g,
+                                                             const float* __restrict__ x, const float* __restrict__ Z,
+                                                             const float* __restrict__ aux,
+                                                             const float* __restrict__ dqp,
+                                                             const float* __restrict__ dsdt, float* __restrict__ out) {
+    __shared__ float sh[16][16][12];
+    const int grp = threadIdx.x >> 4, o = threadIdx.x & 15;
+    float a[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) a[i] = 0.0f;
+    for (int node = blockIdx.x * 16 + grp; node < n; node += gridDim.x * 16) {
+        const float go = g[(size_t)node * 16 + o];
+        const float xv = x[node], zv = Z[node], dq = dqp[node];
+        const float2 sd = reinterpret_cast<const float2*>(dsdt)[node];
+        const float4 ax = reinterpret_cast<const float4*>(aux)[node];
+        a[0] = fmaf(go, xv, a[0]);      // T0[o][0]
+        a[1] = fmaf(go, zv, a[1]);      // T1[o][0]
+        a[2] += go;                     // T2[o][0]
+        a[3] = fmaf(go, ax.w, a[3]);    // T2[o][1]
+        a[4] = fmaf(go, ax.x, a[4]);    // T2[o][2]
+        a[5] = fmaf(dq, xv, a[5]);      // T3[0][0]
+        a[6] += dq;                     // T4[0][0]
+        a[7] = fmaf(sd.x, xv, a[7]);    // T5[0][0]
+        a[8] = fmaf(sd.y, xv, a[8]);    // T5[1][0]
+        a[9] += sd.x;                   // T6[0][0]
+        a[10] += sd.y;                  // T6[1][0]
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) sh[grp][o][i] = a[i];
+    __syncthreads();
+    float* dst = out + (size_t)blockIdx.x * STAT_FLOATS;
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK) dst[i] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 16 * 11) {
+        const int oo = threadIdx.x / 11, i = threadIdx.x % 11;
+        float v = 0.0f;
+        for (int gq = 0; gq < 16; ++gq) v += sh[gq][oo][i];
+        if (i == 0) dst[0 * 256 + oo * 16 + 0] = v;
+        else if (i == 1) dst[1 * 256 + oo * 16 + 0] = v;
+        else if (i <= 4) dst[2 * 256 + oo * 16 + (i - 2)] = v;
+        else if (oo == 0) {   // scalar statistics are identical in every lane of a group: take lane 0
+            if (i == 5) dst[3 * 256] = v;
+            else if (i == 6) dst[4 * 256] = v;
+            else if (i == 7) dst[5 * 256] = v;
+            else if (i == 8) dst[5 * 256 + 16] = v;
+            else if (i == 9) dst[6 * 256] = v;
+            else dst[6 * 256 + 16] = v;
+        }
+    }
+}
+
+int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_dst, const float* g, hipStream_t s) {
+    const int blocks = stat_blocks_for(n_dst);
+    if (cin == 16)
+        hipLaunchKernelGGL(param_stats16_kernel, dim3(blocks), dim3(BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux,
+                           w.dqp, w.dsdt, w.stats);
+    else
+        hipLaunchKernelGGL(param_stats1_kernel, dim3(blocks), dim3(BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux, w.dqp,
+                           w.dsdt, w.stats);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "param_stats");
+}
+
+// -------------------------------------------------------------------------------------------------
+// finalize_conv: fixed-order sum of the per-workgroup partial tiles, then the small matrix algebra
+// (oracle/spmm_form.py::conv_bwd "grads = {...}").  One workgroup.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void finalize_conv_kernel(int cin, ConvParams p, const float* __restrict__ stats,
+                                                              int nblk, float* __restrict__ grads) {
+    __shared__ float T[STAT_FLOATS];
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK) {
+        float v = 0.0f;
+        for (int b = 0; b < nblk; ++b) v += stats[(size_t)b * STAT_FLOATS + i];
+        T[i] = v;
+    }
+    __syncthreads();
+    const float* T0 = T; const float* T1 = T + 256; const float* T2 = T + 512; const float* T3 = T + 768;
+    const float* T4 = T + 1024; const float* T5 = T + 1280; const float* T6 = T + 1536;
+    float* gWk = grads;
+    float* gbk = gWk + 16 * cin;
+    float* gWq = gbk + 16;
+    float* gbq = gWq + 16 * cin;
+    float* gWv = gbq + 16;
+    float* gbv = gWv + 16 * cin;
+    float* gwe = gbv + 16;
+    float* gWs = gwe + 16;
+    float* gbs = gWs + 16 * cin;
+    const int c = threadIdx.x >> 4, j = threadIdx.x & 15;
+    if (j < cin) {
+        gWs[c * cin + j] = T0[c * 16 + j];
+        gWv[c * cin + j] = T1[c * 16 + j];
+        float wk = p.bq[c] * T4[j * 16];           // bq[c] * s_dqp[k=j]
+        float wq = fmaf(p.bk[c], T5[j], p.we[c] * T5[16 + j]);
+        for (int d = 0; d < cin; ++d) wk = fmaf(p.Wq[c * cin + d], T3[j * 16 + d], wk);
+        for (int k = 0; k < cin; ++k) wq = fmaf(p.Wk[c * cin + k], T3[k * 16 + j], wq);
+        gWk[c * cin + j] = 0.25f * wk;
+        gWq[c * cin + j] = 0.25f * wq;
+    }
+    if (j == 0) {
+        gbs[c] = T2[c * 16 + 0];
+        gbv[c] = T2[c * 16 + 1];
+        float bk = p.bq[c] * T6[0], we = p.bq[c] * T6[16];
+        float bq = fmaf(p.bk[c], T6[0], p.we[c] * T6[16]);
+        for (int d = 0; d < cin; ++d) {
+            bk = fmaf(p.Wq[c * cin + d], T5[d], bk);
+            we = fmaf(p.Wq[c * cin + d], T5[16 + d], we);
+        }
+        for (int k = 0; k < cin; ++k) bq = fmaf(p.Wk[c * cin + k], T4[k * 16], bq);
+        gbk[c] = 0.25f * bk;
+        gwe[c] = T2[c * 16 + 2] + 0.25f * we;
+        gbq[c] = 0.25f * bq;
+    }
+}
+
+int launch_finalize_conv(int cin, const float* conv_params, const float* stats, int n_stat_blocks, float* grads,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(finalize_conv_kernel, dim3(1), dim3(BLOCK), 0, s, cin, conv_params_at(conv_params, cin), stats,
+                       n_stat_blocks, grads);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "finalize_conv");
+}
+
+// -------------------------------------------------------------------------------------------------
+// head: z_i = <h_i, w_fc> + b_fc ; BCEWithLogits ; dh_i = dz_i w_fc ; partial sums of dW, db, loss
+// 16 lanes per variable.  partials: [blocks][18] = {dW[16], db, loss}
+// -------------------------------------------------------------------------------------------------
+constexpr int HEAD_BLOCKS_MAX = 1024;
+int head_blocks_for(int64_t n) {
+    int64_t b = (n + 15) / 16;
+    if (b < 1) b = 1;
+    if (b > HEAD_BLOCKS_MAX) b = HEAD_BLOCKS_MAX;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(BLOCK) void head_kernel(int mode, int n, const float* __restrict__ h,
+                                                     const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                     const float* __restrict__ inv_n, const float* __restrict__ labels,
+                                                     float inv_batch, const float* __restrict__ dz_in,
+                                                     float* __restrict__ logits, float* __restrict__ dh,
+                                                     float* __restrict__ partials) {
+    __shared__ float sh[16][18];
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const float w = fcw[c], b = fcb[0];
+    float accw = 0.0f, accb = 0.0f, accl = 0.0f;
+    for (int i = blockIdx.x * 16 + grp; i < n; i += gridDim.x * 16) {
+        const float hv = h[(size_t)i * 16 + c];
+        const float z = row16_sum(hv * w) + b;
+        if (c == 0 && logits) logits[i] = z;
+        if (mode == 0) continue;
+        float dz;
+        if (mode == 1) {
+            dz = dz_in[i];
+        } else {
+            const float y = labels[i];
+            const float wn = inv_n[i] * inv_batch;
+            const float e = expf(-fabsf(z));
+            const float sig = z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+            dz = wn * (sig - y);
+            accl += wn * (fmaxf(z, 0.0f) - z * y + log1pf(e));
+        }
+        dh[(size_t)i * 16 + c] = dz * w;
+        accw = fmaf(dz, hv, accw);
+        accb += dz;
+    }
+    if (mode == 0) return;
+    sh[grp][c] = accw;
+    if (c == 0) {
+        sh[grp][16] = accb;
+        sh[grp][17] = accl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 18) {
+        float v = 0.0f;
+        for (int gq = 0; gq < 16; ++gq) v += sh[gq][threadIdx.x];
+        partials[(size_t)blockIdx.x * 18 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restrict__ partials, int nblk,
+                                                           float* __restrict__ grad_fc, float* __restrict__ loss) {
+    const int i = threadIdx.x;
+    if (i >= 18) return;
+    float v = 0.0f;
+    for (int b = 0; b < nblk; ++b) v += partials[(size_t)b * 18 + i];
+    if (i < 17) grad_fc[i] = v;
+    else if (loss) loss[0] = v;
+}
+
+int launch_head(int mode, int64_t n, const float* h3v, const float* fc_w, const float* fc_b, const float* inv_n,
+                const float* labels, float inv_batch, const float* dlogits_in, float* logits, float* dh3v,
+                float* partials, hipStream_t s) {
+    const int blocks = head_blocks_for(n);
+    hipLaunchKernelGGL(head_kernel, dim3(blocks), dim3(BLOCK), 0, s, mode, (int)n, h3v, fc_w, fc_b, inv_n, labels,
+                       inv_batch, dlogits_in, logits, dh3v, partials);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "head");
+}
+
+int launch_head_finalize(const float* partials, int n_blocks, float* grad_fc, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, partials, n_blocks, grad_fc, loss);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "head_finalize");
+}
+
+// -------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults apart from lr): one workgroup, the step counter lives on the device so
+// that a captured hipGraph can be replayed.  state = {step, lr, beta1, beta2}
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    float* __restrict__ state, float eps, float gscale, int n) {
+    const float step = state[0] + 1.0f, lr = state[1], b1 = state[2], b2 = state[3];
+    __syncthreads();
+    const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+    const float step_size = lr / bc1, rs_bc2 = 1.0f / sqrtf(bc2);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * rs_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+    if (threadIdx.x == 0) state[0] = step;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, float* state, float eps, float gscale, int64_t n,
+                hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(1024), 0, s, p, g, m, v, state, eps, gscale, (int)n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "adam");
+}
+
+__global__ void fill_zero_kernel(float* __restrict__ p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = 0.0f;
+}
+int launch_fill_zero(float* p, int64_t n, hipStream_t s) {
+    if (n <= 0) return MLLP_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "fill_zero");
+}
+
+// -------------------------------------------------------------------------------------------------
+// top-m metrics: one workgroup per instance; 4-pass radix select (8 bits per pass) of the m-th largest
+// logit, then TP / F1.  Ties at the threshold are taken in index order.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned orderable(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(BLOCK) void topm_metrics_kernel(const int* __restrict__ ptr_n, const int* __restrict__ ptr_m,
+                                                             const float* __restrict__ logits,
+                                                             const float* __restrict__ labels, float* __restrict__ out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ float s_red[BLOCK];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int beg = ptr_n[k], n = ptr_n[k + 1] - beg;
+    int m = ptr_m[k + 1] - ptr_m[k];
+    if (m > n) m = n;
+    const float* z = logits + beg;
+    const float* y = labels + beg;
+    if (m <= 0 || n <= 0) {
+        if (tid == 0) { out[2 * k] = 0.0f; out[2 * k + 1] = 0.0f; }
+        return;
+    }
+    if (tid == 0) { s_prefix = 0u; s_need = (unsigned)m; }
+    unsigned mask = 0u;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < n; i += BLOCK) {
+            const unsigned key = orderable(z[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = s_need, cum = 0u;
+            int bsel = 0;
+            for (int b = 255; b >= 0; --b) {
+                if (cum + hist[b] >= need) { bsel = b; break; }
+                cum += hist[b];
+            }
+            s_need = need - cum;
+            s_prefix = prefix | ((unsigned)bsel << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;
+    const unsigned need_eq = s_need;   // how many keys equal to thr belong to the top-m (>= 1)
+    float tp = 0.0f, ysum = 0.0f, eqc = 0.0f, eqy = 0.0f;
+    for (int i = tid; i < n; i += BLOCK) {
+        const unsigned key = orderable(z[i]);
+        const float yi = y[i];
+        ysum += yi;
+        if (key > thr) tp += yi;
+        else if (key == thr) { eqc += 1.0f; eqy += yi; }
+    }
+    float vals[4] = {tp, ysum, eqc, eqy};
+    float tot[4];
+    for (int q = 0; q < 4; ++q) {
+        s_red[tid] = vals[q];
+        __syncthreads();
+        for (int st = BLOCK / 2; st > 0; st >>= 1) {
+            if (tid < st) s_red[tid] += s_red[tid + st];
+            __syncthreads();
+        }
+        tot[q] = s_red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float TP = tot[0];
+        if ((unsigned)tot[2] == need_eq) TP += tot[3];
+        else {   // rare: tie at the threshold, take the first need_eq in index order
+            unsigned taken = 0;
+            for (int i = 0; i < n && taken < need_eq; ++i)
+                if (orderable(z[i]) == thr) { TP += y[i]; ++taken; }
+        }
+        const float FP = (float)m - TP, FN = tot[1] - TP;
+        const float den = 2.0f * TP + FP + FN;
+        out[2 * k] = TP;
+        out[2 * k + 1] = den > 0.0f ? 2.0f * TP / den : 0.0f;
+    }
+}
+
+int launch_topm_metrics(const mllp_graph* g, const float* logits, const float* labels, void* scratch, float* out,
+                        hipStream_t s) {
+    (void)scratch;
+    if (g->n_inst == 0) return MLLP_OK;
+    hipLaunchKernelGGL(topm_metrics_kernel, dim3((unsigned)g->n_inst), dim3(BLOCK), 0, s, g->inst_ptr_n, g->inst_ptr_m,
+                       logits, labels, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "topm_metrics");
+}
+
+}  // namespace mllp

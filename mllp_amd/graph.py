@@ -1,0 +1,245 @@
+"""HBM-resident batch of LP instances (block-diagonal constraint matrix, both orientations).
+
+`LPBatch` replaces the reference's per-step graph build
+(`build_graph_from_weights_sets`, reference linear_program_methods.py:89-103) and the
+`BipartiteData.__inc__` batching rule (methods.py:60-72): the batch is built once, lives in HBM as
+CSR(A) + CSR(A^T) behind an opaque `mllp_graph_t*`, and every model call takes it by handle.
+"""
+import ctypes
+from ctypes import c_int32, c_int64, c_double, c_void_p
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import LPInstance
+
+
+class LPBatch:
+    def __init__(self, handle, M, N, nnz, n_inst, inst_m, inst_n, x1, x2, labels, names=None):
+        self._h = handle
+        self.M, self.N, self.nnz, self.n_inst = int(M), int(N), int(nnz), int(n_inst)
+        self.inst_m = [int(v) for v in inst_m]
+        self.inst_n = [int(v) for v in inst_n]
+        self.x1, self.x2, self.labels = x1, x2, labels      # cuda fp32: coefs (N,), rhs (M,), basis (N,)
+        self.names = list(names) if names is not None else [f"inst{i}" for i in range(n_inst)]
+        self._ws = None
+        self._n_off = np.concatenate([[0], np.cumsum(self.inst_n)]).astype(np.int64)
+
+    # ---- construction ------------------------------------------------------------------------
+    @staticmethod
+    def from_instances(instances: Sequence[LPInstance], device="cuda", tier_wave=0, tier_block=0) -> "LPBatch":
+        L = _lib.lib()
+        inst_m = np.array([i.m for i in instances], dtype=np.int64)
+        inst_n = np.array([i.n for i in instances], dtype=np.int64)
+        indptr = np.ascontiguousarray(np.concatenate([i.indptr.astype(np.int64) for i in instances]))
+        indices = np.ascontiguousarray(np.concatenate([i.indices.astype(np.int32) for i in instances]))
+        values = np.ascontiguousarray(np.concatenate([i.values.astype(np.float64) for i in instances]))
+        if indices.size == 0:
+            indices, values = np.zeros(1, np.int32), np.zeros(1, np.float64)
+        torch.cuda.init()
+        h = c_void_p()
+        _lib.check(L.mllp_graph_create_host(len(instances), _lib.np_ptr(inst_m, c_int64), _lib.np_ptr(inst_n, c_int64),
+                                            _lib.np_ptr(indptr, c_int64), _lib.np_ptr(indices, c_int32),
+                                            _lib.np_ptr(values, c_double), tier_wave, tier_block, ctypes.byref(h)))
+        # fp32 casts as reference methods.py:90-91,100
+        x1 = torch.tensor(np.concatenate([i.coefs for i in instances]), dtype=torch.float32, device=device)
+        x2 = torch.tensor(np.concatenate([i.rhs for i in instances]), dtype=torch.float32, device=device)
+        y = torch.tensor(np.concatenate([i.basis for i in instances]), dtype=torch.float32, device=device)
+        return LPBatch(h, inst_m.sum(), inst_n.sum(), sum(i.nnz for i in instances), len(instances), inst_m, inst_n,
+                       x1, x2, y, [i.name for i in instances])
+
+    @staticmethod
+    def from_device_csr(inst_m, inst_n, csr_ptr, csr_idx, csr_val, x1, x2, labels, tier_wave=0, tier_block=0,
+                        names=None) -> "LPBatch":
+        """Batch from device CSR arrays in global ids (int32 ptr/idx, fp32 values).  The transposed
+        orientation is built here with one stable device sort (torch -> rocPRIM): plumbing, done once."""
+        L = _lib.lib()
+        M, N, nnz = int(sum(inst_m)), int(sum(inst_n)), int(csr_idx.numel())
+        rows = torch.repeat_interleave(torch.arange(M, device=csr_idx.device, dtype=torch.int32),
+                                       (csr_ptr[1:] - csr_ptr[:-1]).long())
+        order = torch.sort(csr_idx.long(), stable=True)[1]        # stable: row ids ascend inside a column
+        csc_idx = rows[order].contiguous()
+        csc_val = csr_val[order].contiguous()
+        counts = torch.bincount(csr_idx.long(), minlength=N)
+        csc_ptr = torch.zeros(N + 1, dtype=torch.int32, device=csr_idx.device)
+        csc_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        del rows, order, counts
+        pm = np.concatenate([[0], np.cumsum(inst_m)]).astype(np.int64)
+        pn = np.concatenate([[0], np.cumsum(inst_n)]).astype(np.int64)
+        h = c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(L.mllp_graph_create_device(len(inst_m), _lib.np_ptr(pm, c_int64), _lib.np_ptr(pn, c_int64), nnz,
+                                              _lib.ptr(csr_ptr), _lib.ptr(csr_idx), _lib.ptr(csr_val),
+                                              _lib.ptr(csc_ptr), _lib.ptr(csc_idx), _lib.ptr(csc_val),
+                                              tier_wave, tier_block, _lib.current_stream(), ctypes.byref(h)))
+        torch.cuda.synchronize()
+        return LPBatch(h, M, N, nnz, len(inst_m), inst_m, inst_n, x1, x2, labels, names)
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._h.value:
+                _lib.lib().mllp_graph_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- introspection -----------------------------------------------------------------------
+    def dims(self):
+        d = (c_int64 * 10)()
+        _lib.check(_lib.lib().mllp_graph_dims(self._h, d))
+        keys = ["M", "N", "nnz", "n_inst", "A_group", "A_wave", "A_block", "At_group", "At_wave", "At_block"]
+        return dict(zip(keys, [int(v) for v in d]))
+
+    def export(self, which):
+        sizes = {0: (self.M + 1, np.int32), 1: (self.nnz, np.int32), 2: (self.nnz, np.float32),
+                 3: (self.N + 1, np.int32), 4: (self.nnz, np.int32), 5: (self.nnz, np.float32),
+                 6: (self.N, np.float32)}
+        n, dt = sizes[which]
+        out = np.empty(n, dtype=dt)
+        _lib.check(_lib.lib().mllp_graph_export(self._h, which, out.ctypes.data_as(c_void_p), out.nbytes))
+        return out
+
+    def logits_per_instance(self, logits):
+        return [logits[self._n_off[k]:self._n_off[k + 1]] for k in range(self.n_inst)]
+
+    # ---- primitives --------------------------------------------------------------------------
+    def spmm(self, H: torch.Tensor, transpose=False, out: Optional[torch.Tensor] = None):
+        """Y = A @ H (transpose=False, H [N,16]) or A^T @ H (H [M,16])."""
+        n_in, n_out = (self.M, self.N) if transpose else (self.N, self.M)
+        assert H.is_cuda and H.dtype == torch.float32 and H.is_contiguous() and tuple(H.shape) == (n_in, 16)
+        if out is None:
+            out = torch.empty(n_out, 16, device=H.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_spmm_csr_f32(self._h, int(transpose), _lib.ptr(H), _lib.ptr(out),
+                                                _lib.current_stream()))
+        return out
+
+    def tconv_workspace(self, dst_is_var, cin):
+        n = c_int64()
+        _lib.check(_lib.lib().mllp_tconv_workspace_floats(self._h, int(dst_is_var), cin, ctypes.byref(n)))
+        return torch.empty(n.value, device=self.x1.device, dtype=torch.float32)
+
+    def tconv_fwd(self, dst_is_var, cin, conv_params, x_src, x_dst, ws):
+        n_dst = self.N if dst_is_var else self.M
+        h = torch.empty(n_dst, 16, device=x_src.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_tconv_fwd(self._h, int(dst_is_var), cin, _lib.ptr(conv_params), _lib.ptr(x_src),
+                                             _lib.ptr(x_dst), _lib.ptr(h), _lib.ptr(ws), _lib.current_stream()))
+        return h
+
+    def tconv_bwd(self, dst_is_var, cin, conv_params, x_src, x_dst, h, ws, dh, want_input_grads=True):
+        n_dst, n_src = (self.N, self.M) if dst_is_var else (self.M, self.N)
+        dh = dh.clone()
+        dxd = torch.empty(n_dst, cin, device=dh.device) if (want_input_grads and cin == 16) else None
+        dxs = torch.empty(n_src, cin, device=dh.device) if (want_input_grads and cin == 16) else None
+        pg = torch.empty(conv_params.numel(), device=dh.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_tconv_bwd(self._h, int(dst_is_var), cin, _lib.ptr(conv_params), _lib.ptr(x_src),
+                                             _lib.ptr(x_dst), _lib.ptr(h), _lib.ptr(ws), _lib.ptr(dh), _lib.ptr(dxd),
+                                             _lib.ptr(dxs), 0, _lib.ptr(pg), _lib.current_stream()))
+        return pg, dxd, dxs, dh
+
+    # ---- whole model -------------------------------------------------------------------------
+    def workspace(self):
+        if self._ws is None:
+            n = c_int64()
+            _lib.check(_lib.lib().mllp_gnn_workspace_bytes(self._h, ctypes.byref(n)))
+            self._ws = torch.empty(n.value // 4, device=self.x1.device, dtype=torch.float32)
+        return self._ws
+
+    def forward(self, params: torch.Tensor, logits: Optional[torch.Tensor] = None):
+        assert params.is_cuda and params.dtype == torch.float32 and params.numel() == _lib.NUM_PARAMS
+        if logits is None:
+            logits = torch.empty(self.N, device=params.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_gnn_forward(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
+                                               _lib.ptr(self.workspace()), _lib.ptr(logits), _lib.current_stream()))
+        return logits
+
+    def backward(self, params, dlogits, grads: Optional[torch.Tensor] = None):
+        if grads is None:
+            grads = torch.empty(_lib.NUM_PARAMS, device=params.device, dtype=torch.float32)
+        dlogits = dlogits.contiguous().float()
+        _lib.check(_lib.lib().mllp_gnn_backward(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
+                                                _lib.ptr(self.workspace()), _lib.ptr(dlogits), _lib.ptr(grads),
+                                                _lib.current_stream()))
+        return grads
+
+    def loss_step(self, params, inv_batch=None, logits=None, loss=None, grads=None):
+        """forward + BCEWithLogits + backward.  loss = inv_batch * sum_k mean_i BCE; default 1/n_inst."""
+        dev = params.device
+        logits = torch.empty(self.N, device=dev, dtype=torch.float32) if logits is None else logits
+        loss = torch.empty(1, device=dev, dtype=torch.float32) if loss is None else loss
+        grads = torch.empty(_lib.NUM_PARAMS, device=dev, dtype=torch.float32) if grads is None else grads
+        ib = (1.0 / self.n_inst) if inv_batch is None else float(inv_batch)
+        _lib.check(_lib.lib().mllp_gnn_loss_step(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
+                                                 _lib.ptr(self.labels), ib, _lib.ptr(self.workspace()),
+                                                 _lib.ptr(logits), _lib.ptr(loss), _lib.ptr(grads),
+                                                 _lib.current_stream()))
+        return loss, logits, grads
+
+    def topm_metrics(self, logits, out=None):
+        """[n_inst, 2] = (correct_num, f1) per instance (reference experiment.py:146-151)."""
+        if out is None:
+            out = torch.empty(self.n_inst, 2, device=logits.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_topm_metrics(self._h, _lib.ptr(logits), _lib.ptr(self.labels), c_void_p(0),
+                                                _lib.ptr(out), _lib.current_stream()))
+        return out
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, state, eps=1e-8, grad_scale=1.0):
+    """state: cuda float tensor [step, lr, beta1, beta2]; step is incremented on the device."""
+    _lib.check(_lib.lib().mllp_adam_step(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                         _lib.ptr(state), eps, grad_scale, params.numel(), _lib.current_stream()))
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic batches generated on the device (BASELINE.json configs[3]/[4])
+# ----------------------------------------------------------------------------------------------
+def synthetic_batch(n_inst=256, m=10000, n=20000, mean_row_nnz=200.0, seed=1234, device="cuda",
+                    chunk=16, tier_wave=0, tier_block=0) -> LPBatch:
+    """Random sparse LPs with Netlib-like statistics, generated on the GPU.
+
+    Each row's columns come from a Bernoulli(p = mean_row_nnz / n) process realised as geometric gaps
+    (row nnz ~ Binomial(n, p) ~ Poisson(mean), at least 1), values N(0,1) scaled to unit row 2-norm,
+    coefs N(0,1) with 45% zeros then unit norm per instance, rhs 0 w.p. 0.73 else U(0,5), labels
+    Bernoulli(0.37).  Instance i uses seed `seed + i` for its pattern chunk."""
+    p = mean_row_nnz / n
+    L = int(mean_row_nnz + 10 * np.sqrt(mean_row_nnz) + 16)     # gap slots per row (covers > 9 sigma)
+    ptr_parts, idx_parts, val_parts = [], [], []
+    nnz_off = 0
+    log1mp = float(np.log1p(-p))
+    for c0 in range(0, n_inst, chunk):
+        k = min(chunk, n_inst - c0)
+        g = torch.Generator(device=device).manual_seed(seed + c0)
+        u = torch.rand(k * m, L, device=device, generator=g).clamp_(min=1e-12)
+        gaps = torch.floor(torch.log(u) / log1mp).to(torch.int32) + 1          # geometric(p) >= 1
+        cols = torch.cumsum(gaps, dim=1, dtype=torch.int32) - 1
+        del u, gaps
+        keep = cols < n
+        keep[:, 0] = True                                                    # at least one nonzero per row
+        cols[:, 0].clamp_(max=n - 1)
+        cnt = keep.sum(dim=1)
+        inst_of_row = torch.arange(k * m, device=device, dtype=torch.int64) // m
+        gcols = (cols + ((c0 + inst_of_row) * n).to(torch.int32)[:, None])[keep]
+        vals = torch.randn(gcols.numel(), device=device, generator=g)
+        rows = torch.repeat_interleave(torch.arange(k * m, device=device), cnt)
+        nrm = torch.zeros(k * m, device=device).index_add_(0, rows, vals * vals).sqrt_().clamp_(min=1e-12)
+        vals = vals / nrm[rows]
+        ptr = torch.cumsum(cnt, 0) + nnz_off
+        nnz_off = int(ptr[-1])
+        ptr_parts.append(ptr.to(torch.int32))
+        idx_parts.append(gcols.to(torch.int32))
+        val_parts.append(vals)
+        del cols, keep, rows, nrm, inst_of_row
+    csr_ptr = torch.cat([torch.zeros(1, dtype=torch.int32, device=device)] + ptr_parts)
+    csr_idx, csr_val = torch.cat(idx_parts), torch.cat(val_parts)
+    del ptr_parts, idx_parts, val_parts
+    g = torch.Generator(device=device).manual_seed(seed + 7919)
+    N, M = n_inst * n, n_inst * m
+    x1 = torch.randn(N, device=device, generator=g)
+    x1[torch.rand(N, device=device, generator=g) < 0.45] = 0.0
+    x1 = (x1.view(n_inst, n) / x1.view(n_inst, n).norm(dim=1, keepdim=True).clamp_(min=1e-12)).reshape(-1).contiguous()
+    x2 = torch.where(torch.rand(M, device=device, generator=g) < 0.73, torch.zeros(M, device=device),
+                     torch.rand(M, device=device, generator=g) * 5.0)
+    y = (torch.rand(N, device=device, generator=g) < 0.37).float()
+    return LPBatch.from_device_csr([m] * n_inst, [n] * n_inst, csr_ptr, csr_idx, csr_val, x1, x2, y,
+                                   tier_wave, tier_block, names=[f"synth{seed + i}" for i in range(n_inst)])

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- LP instances/s (forward + backward + Adam) on the Netlib batch, and achieved HBM GB/s
+of the CSR SpMM on the synthetic roofline batch (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0:
+  value        whole-job LP instances/s on the full Netlib batch (BASELINE.json configs[2], 97 instances,
+               one block-diagonal batch per rank and step, fp32), inputs resident in HBM, K steps timed
+               between barrier + synchronize pairs, max over ranks.  Weak scaling: every rank owns one
+               Netlib batch per step (97 instances per GPU), gradients all-reduced over RCCL each step.
+  roofline     plain CSR SpMM  Y = A H  on the synthetic batch (configs[3]: m=10k, n=20k, ~1% dense,
+               256 instances per GPU): algorithmic bytes / average launch duration, HIP events on the
+               launch stream, against the 8 TB/s HBM3E peak.  `kernels` lists the other sweeps likewise.
+  synthetic    LP instances/s of the full training step on that synthetic batch (configs[3]; with N
+               ranks it is configs[4]: 256 instances per GPU, weak scaling).
+  cpu_baseline the oracle's literal restatement of the reference loop (per-instance graph rebuild,
+               forward, BCE, autograd backward, Adam; reference linear_program_experiment.py:120-144)
+               timed on this host for one epoch of the same 97 instances (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--synthetic-instances", type=int, default=256, help="instances per GPU of the roofline batch")
+    ap.add_argument("--synthetic-steps", type=int, default=5)
+    ap.add_argument("--spmm-reps", type=int, default=10)
+    ap.add_argument("--no-synthetic", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hip-graph", action="store_true")
+    return ap.parse_args()
+
+
+def timed(fn, reps, warm=2):
+    """average ms per call of fn(), HIP events on the current (launch) stream"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def barrier_sync(dist_on):
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, dist_on):
+    if not dist_on:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def spmm_bytes(nnz, rows, cols, C=16):
+    # nnz (4 B index + 4 B value) + row pointers + source rows once + output rows once
+    return nnz * 8 + 4 * (rows + 1) + cols * C * 4 + rows * C * 4
+
+
+def load_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(p) as fh:
+            return json.load(fh).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(instances):
+    from oracle import pyg_restatement as o1
+    sd = o1.init_state(42, torch.float32)
+    tr = o1.ReferenceTrainer(sd, lr=1e-3, dtype=torch.float32, rebuild_graph=True)
+    small = sorted(instances, key=lambda i: i.nnz)[:3]
+    for i in small:            # warm-up (allocator, thread pool)
+        tr.step(i)
+    t0 = time.perf_counter()
+    for i in instances:
+        tr.step(i)
+    dt = time.perf_counter() - t0
+    return dict(value=len(instances) / dt, unit="instances/s", cores=int(torch.get_num_threads()),
+                host_cpus=os.cpu_count(), kind="port", seconds=dt,
+                sample=f"1 epoch of the same {len(instances)} Netlib instances, one Adam step per instance, "
+                       "graph rebuilt per step (reference experiment.py:123-144), fp32 torch CPU; "
+                       "PyG itself is not installable here, so this is the oracle's restatement")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from mllp_amd import _lib
+    _lib.lib()   # fail loudly if the HIP library is missing
+    from mllp_amd.data import load_packed
+    from mllp_amd.graph import LPBatch, synthetic_batch
+    from mllp_amd.trainer import LPTrainer
+    from oracle.pyg_restatement import flatten_state, init_state
+
+    params0 = flatten_state(init_state(42, torch.float32)).cuda()
+    instances = load_packed()
+    n_inst = len(instances)
+
+    # ---------------- headline: Netlib batch, instances/s --------------------------------------
+    batch = LPBatch.from_instances(instances)
+    trainer = LPTrainer(params0, lr=1e-3, use_hip_graph=not args.no_hip_graph, global_instances=n_inst * world)
+    for _ in range(max(args.warmup, 2)):          # >= 2: eager pass + graph capture
+        trainer.step(batch)
+    barrier_sync(dist_on)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(batch)
+    barrier_sync(dist_on)
+    dt = max_over_ranks(time.perf_counter() - t0, dist_on)
+    loss_end = float(trainer._plans[id(batch)]["loss"][0])
+    value = n_inst * world * args.steps / dt
+    out = {
+        "metric": "LP instances/sec (fwd+bwd) on Netlib batch; achieved HBM GB/s on CSR SpMM",
+        "value": value, "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "Netlib LP (97 normalized instances packed in data/netlib_norm.npz); "
+                                "synthetic sparse LPs for the roofline section",
+        "config": {"workload": "netlib_full: BASELINE.json configs[2], 97 instances / 1,074,147 nnz as one "
+                               "block-diagonal batch per GPU and step, fwd + BCE + bwd + Adam, fp32",
+                   "instances_per_gpu": n_inst, "nnz_per_gpu": batch.nnz, "hip_graph": not args.no_hip_graph,
+                   "parallelism": f"dp{world}", "final_loss_rank0": loss_end},
+    }
+    del trainer
+
+    # ---------------- roofline + synthetic throughput ------------------------------------------
+    if not args.no_synthetic:
+        t_gen = time.perf_counter()
+        sb = synthetic_batch(args.synthetic_instances, seed=1234 + 100000 * rank)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t_gen
+        Hn = torch.randn(sb.N, 16, device="cuda")
+        Hm = torch.randn(sb.M, 16, device="cuda")
+        Ym = torch.empty(sb.M, 16, device="cuda")
+        Yn = torch.empty(sb.N, 16, device="cuda")
+        ms_a = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps)
+        ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps)
+        b_a, b_at = spmm_bytes(sb.nnz, sb.M, sb.N), spmm_bytes(sb.nnz, sb.N, sb.M)
+        gbs_a, gbs_at = b_a / ms_a / 1e6, b_at / ms_at / 1e6
+        kernels = [
+            {"kernel": "spmm_csr A*H", "ms": ms_a, "alg_bytes": b_a, "GBps": gbs_a, "frac": gbs_a / HBM_PEAK_GBS},
+            {"kernel": "spmm_csr At*H", "ms": ms_at, "alg_bytes": b_at, "GBps": gbs_at, "frac": gbs_at / HBM_PEAK_GBS},
+        ]
+        del Ym, Yn
+        # one attention conv forward / backward (16-wide), destination = constraints
+        cp = params0[1392:1392 + 1104].contiguous()
+        ws = sb.tconv_workspace(False, 16)
+        h = [None]
+
+        def conv_f():
+            h[0] = sb.tconv_fwd(False, 16, cp, Hn, Hm, ws)
+        ms_f = timed(conv_f, 3, warm=1)
+        # forward bytes: pattern + source rows once + per destination: node_qp (x read, q' and t written) and the
+        # sweep (q', t, x read; h, Z, aux written) = 132 + 132 + 144 = 408 B
+        b_f = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 64 + sb.M * 408
+        kernels.append({"kernel": "tconv_fwd16 (prep + node_qp + attn sweep), dst=constraints", "ms": ms_f,
+                        "alg_bytes": b_f, "GBps": b_f / ms_f / 1e6, "frac": b_f / ms_f / 1e6 / HBM_PEAK_GBS})
+        del ws, h, Hm
+        out["roofline"] = {"bound": "hbm", "kernel": "sweep_kernel<SpmmOp> (plain CSR SpMM, Y = A*H, C=16, fp32)",
+                           "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
+                                       f"nnz={sb.nnz}", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs_a / HBM_PEAK_GBS, "alg_bytes_per_launch": b_a, "ms_per_launch": ms_a,
+                           "traffic": load_traffic("spmm_csr"), "kernels": kernels}
+        del Hn
+        # full training step on the synthetic batch
+        tr = LPTrainer(params0, lr=1e-3, use_hip_graph=False, global_instances=sb.n_inst * world)
+        for _ in range(2):
+            tr.step(sb)
+        barrier_sync(dist_on)
+        t0 = time.perf_counter()
+        for _ in range(args.synthetic_steps):
+            tr.step(sb)
+        barrier_sync(dist_on)
+        dts = max_over_ranks(time.perf_counter() - t0, dist_on)
+        out["synthetic"] = {"workload": "configs[3] per GPU (configs[4] at 8 GPUs): fwd + BCE + bwd + Adam",
+                            "instances_per_gpu": sb.n_inst, "nnz_per_gpu": sb.nnz, "steps": args.synthetic_steps,
+                            "ms_per_step": 1e3 * dts / args.synthetic_steps,
+                            "value": sb.n_inst * world * args.synthetic_steps / dts, "unit": "instances/s",
+                            "generate_s": t_gen}
+        del tr, sb
+        torch.cuda.empty_cache()
+
+    # ---------------- CPU baseline (rank 0, single-GPU runs only) ------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(instances)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""CPU: host-side logic of the drop-in surface -- config, loader, graph build, sharding, flat Adam,
+and the data-parallel step (world_size 2 over gloo, gradients from the oracle)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from mllp_amd import config as cfgmod
+from mllp_amd import data as datamod
+from mllp_amd.trainer import FlatAdam, shard_instances
+from oracle import pyg_restatement as o1
+from oracle import spmm_form as o2
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_config_roundtrip(tmp_path):
+    y = tmp_path / "c.yaml"
+    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 3\nmethods:\n  - 'gs-topk'\nnest:\n  a: 1\n")
+    cfg = cfgmod.cfg_from_file(str(y))
+    assert cfg.train_data_type == "netlib" and cfg.train_lr == 1e-3 and cfg.methods[0] == "gs-topk"
+    assert cfg.nest.a == 1 and cfg.get_default("batch_size") == 1
+    with pytest.raises(AttributeError):
+        cfg.missing_key
+    with pytest.raises(ValueError, match="Please specify path to the configuration file!"):
+        cfgmod.load_config([])
+    assert cfgmod.load_config(["--config", str(y)]).train_iter == 3
+    base = cfgmod.AttrDict({"train_lr": 0.5, "nest": {"a": 0, "b": 2}})
+    cfgmod.cfg_from_file(str(y), base)
+    assert base.train_lr == 1e-3 and base.nest.a == 1 and base.nest.b == 2
+
+
+def test_shipped_yaml_selects_the_sparse_path():
+    cfg = cfgmod.cfg_from_file(os.path.join(ROOT, "linear_program_netlib.yaml"))
+    assert cfg.train_data_type == "netlib" and cfg.methods[0] in ("gs-topk", "soft-topk")
+    assert cfg.train_lr == 1e-3 and cfg.train_iter > 0
+
+
+def test_loader_contract(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)          # no reference layout here -> packed fixture
+    dataset, train_dict = datamod.get_netlib_dataset(normalize=True)
+    assert len(dataset) == 97 and list(train_dict)[0] == "obj" and len(train_dict) == 98
+    names = [t[0] for t in dataset]
+    assert names == sorted(names)
+    name, constrs, w, coefs, rhs, basis = dataset[names.index("afiro.mps")]
+    assert len(constrs) == 27 == len(rhs) and len(coefs) == 51 == len(basis) and len(w) == 102
+    assert constrs[0].dtype == np.int32 and w.dtype == np.float64 and basis.dtype == np.int32
+    assert set(np.unique(basis)) <= {0, 1}
+    with pytest.raises(NotImplementedError):
+        datamod.get_netlib_dataset_dense()
+
+
+def test_loader_reads_reference_layout_when_present(tmp_path, monkeypatch):
+    """same files, same naming as reference linear_program_data.py:59-77"""
+    import scipy.sparse as sp
+    inst = datamod.load_packed(["afiro.mps", "sc50a.mps"])
+    os.makedirs(tmp_path / "netlib_mps")
+    os.makedirs(tmp_path / "dataset" / "netlib_mps_norm")
+    for i in inst:
+        (tmp_path / "netlib_mps" / i.name).write_text("")
+        base = str(tmp_path / "dataset" / "netlib_mps_norm" / i.name)
+        np.save(base + "_basis.npy", i.basis)
+        np.save(base + "_coefs.npy", i.coefs)
+        np.save(base + "_rhs.npy", i.rhs)
+        sp.save_npz(base + "_constrs.npz", sp.csr_matrix((i.values, i.indices, i.indptr), shape=(i.m, i.n)))
+    monkeypatch.chdir(tmp_path)
+    dataset, _ = datamod.get_netlib_dataset(True)
+    assert [t[0] for t in dataset] == ["afiro.mps", "sc50a.mps"]
+    for t, i in zip(dataset, inst):
+        got = datamod.LPInstance.from_reference_tuple(t)
+        np.testing.assert_array_equal(got.indptr, i.indptr)
+        np.testing.assert_array_equal(got.indices, i.indices)
+        np.testing.assert_array_equal(got.values, i.values)
+
+
+def test_build_graph_matches_oracle_and_batches(subset5):
+    from mllp_amd.model import BipartiteData, build_graph_from_weights_sets
+    graphs = []
+    for inst in subset5:
+        name, constrs, w, coefs, rhs, basis = inst.as_reference_tuple()
+        g = build_graph_from_weights_sets(constrs, w, rhs, coefs)
+        ei, x1, x2, ea = o1.build_graph_literal(constrs, w, rhs, coefs)
+        assert type(g) == BipartiteData
+        assert torch.equal(g.edge_index, ei) and torch.equal(g.x1, x1) and torch.equal(g.x2, x2)
+        assert torch.equal(g.edge_attr, ea)
+        assert g.__inc__("edge_index").tolist() == [[inst.n], [inst.m]]
+        graphs.append(g)
+    b = BipartiteData.batch(graphs)
+    ref = o1.batch_graphs([(g.edge_index, g.x1, g.x2, g.edge_attr) for g in graphs])
+    assert torch.equal(b.edge_index, ref[0]) and torch.equal(b.x1, ref[1]) and torch.equal(b.edge_attr, ref[3])
+
+
+def test_gnnmodel_state_dict_keys_match_pyg_names():
+    from mllp_amd.model import GNNModel
+    m = GNNModel()
+    spec = o1.state_dict_spec()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _ in spec]
+    assert [tuple(v.shape) for v in sd.values()] == [s for _, s in spec]
+    assert m.flat_parameters().numel() == 4721
+    flat = torch.arange(4721, dtype=torch.float32)
+    m.load_flat(flat)
+    assert torch.equal(m.flat_parameters(), flat)
+    with pytest.raises(Exception):          # no CPU fallback
+        from mllp_amd.model import BipartiteData
+        m(BipartiteData(torch.zeros(2, 0, dtype=torch.long), torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(0, 1)))
+
+
+def test_shard_instances_balanced_and_complete():
+    inst = datamod.load_packed()
+    sizes = [i.nnz for i in inst]
+    for w in (1, 2, 4, 8):
+        sh = shard_instances(sizes, w)
+        assert sorted(sum(sh, [])) == list(range(len(inst)))
+        loads = [sum(sizes[i] for i in s) for s in sh]
+        assert max(loads) <= sum(sizes) / w + max(sizes)        # LPT bound
+    assert shard_instances(sizes, 8) == shard_instances(sizes, 8)
+
+
+def test_flat_adam_torch_backend_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(100, generator=g, dtype=torch.float64)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    mine = FlatAdam(p0.clone(), lr=1e-3, backend="torch")
+    for step in range(5):
+        gr = torch.randn(100, generator=g, dtype=torch.float64)
+        ref.grad = gr.clone()
+        opt.step()
+        mine.step(gr)
+    np.testing.assert_allclose(mine.params.numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)   # state[] is fp32
+    assert float(mine.state[0]) == 5.0
+
+
+_DP_WORKER = textwrap.dedent("""
+    import os, sys, numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from mllp_amd.data import load_packed, SUBSET5
+    from mllp_amd.trainer import DataParallelStep, shard_instances
+    from oracle import pyg_restatement as o1, spmm_form as o2
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    inst = load_packed(SUBSET5)
+    mine = [inst[i] for i in shard_instances([i.nnz for i in inst], world)[rank]]
+    params = o1.flatten_state(o1.init_state(42, torch.float64)).clone()
+    def grad_fn(p):
+        sd = {{k: v.numpy() for k, v in o1.unflatten_state(p).items()}}
+        b = o2.BatchCSR(mine)
+        b.wnode = b.wnode * len(mine) / len(inst)        # divide by the GLOBAL instance count
+        r = o2.gnn_forward_backward(sd, b)
+        return torch.tensor([r["loss"]], dtype=torch.float64), torch.tensor(r["grads"])
+    dp = DataParallelStep(params, grad_fn, lr=1e-3, adam_backend="torch")
+    losses = [float(dp.step()[0]) for _ in range(3)]
+    if rank == 0:
+        np.savez({out!r}, params=params.numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+""")
+
+
+def test_data_parallel_world2_equals_single_process(tmp_path, subset5):
+    """2 gloo ranks, each with its LPT shard of the 5-instance batch: after 3 steps the replicated
+    weights equal the 1-process result (sum of per-shard flat grads == batch grads)."""
+    out = str(tmp_path / "dp.npz")
+    script = tmp_path / "w.py"
+    script.write_text(_DP_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    params = o1.flatten_state(o1.init_state(42, torch.float64)).numpy().copy()
+    m, v, losses = np.zeros_like(params), np.zeros_like(params), []
+    for step in (1, 2, 3):
+        sd = {k: t.numpy() for k, t in o1.unflatten_state(torch.tensor(params)).items()}
+        res = o2.gnn_forward_backward(sd, o2.BatchCSR(subset5))
+        losses.append(res["loss"])
+        o2.adam_step(params, res["grads"], m, v, step, lr=1e-3)
+    np.testing.assert_allclose(got["losses"], losses, rtol=1e-7)   # FlatAdam keeps lr, betas in fp32
+    # lin_key.bias gradients are rounding noise (dead parameter); Adam turns noise into O(lr) moves
+    keep, off = np.ones(params.size, bool), 0
+    for k, s in o1.state_dict_spec():
+        c = int(np.prod(s))
+        if k.endswith("lin_key.bias"):
+            keep[off:off + c] = False
+        off += c
+    np.testing.assert_allclose(got["params"][keep], params[keep], rtol=1e-5, atol=1e-7)

@@ -17,7 +17,8 @@
  *   - every launch is asynchronous on the hipStream_t passed as `stream` (void*; NULL = default
  *     stream); no entry point synchronises except mllp_graph_create_* / mllp_graph_export.
  *   - all launch functions are hipGraph-capturable (no malloc/free/sync inside).
- *   - a mllp_graph_t is immutable after creation; it may be used from several streams.
+ *   - a mllp_graph_t is immutable after creation except for an internal scratch buffer used by
+ *     rows that are split over several workgroups: calls on ONE graph must be stream-ordered.
  *   - feature width is fixed at 16 (reference linear_program_methods.py:206-211), fp32 everywhere.
  *   - there is NO CPU fallback: without a HIP device every launch function fails with MLLP_EHIP.
  */
@@ -60,7 +61,8 @@ int mllp_abi_version(void);
  *   indices : concatenation of LOCAL column ids (row-major, sorted within a row, no duplicates)
  *   values  : float64 entries a_ij (cast to fp32 as linear_program_methods.py:100 does)
  *   tier_wave, tier_block : rows with more than tier_wave nonzeros are processed by one 64-lane
- *     wavefront, more than tier_block by one 256-thread workgroup; 0 = choose automatically.   */
+ *     wavefront, more than tier_block by 256-thread workgroups (one per chunk of at most
+ *     4 * tier_block nonzeros; longer rows are split and merged); 0 = choose automatically.    */
 int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, const int64_t* inst_n,
                            const int64_t* indptr, const int32_t* indices, const double* values,
                            int32_t tier_wave, int32_t tier_block, mllp_graph_t** out);
@@ -76,10 +78,11 @@ int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_m, const in
 
 int mllp_graph_destroy(mllp_graph_t* g);
 
-/* dims[0..9] = M (constraints), N (variables), nnz, n_inst,
- *              rows in tier group/wave/block for A (dst = constraints),
- *              rows in tier group/wave/block for A^T (dst = variables)                         */
-int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[10]);
+/* dims[0..11] = M (constraints), N (variables), nnz, n_inst,
+ *               group-tier rows / wave-tier rows / chunk work items for A (dst = constraints),
+ *               the same three for A^T (dst = variables),
+ *               rows split over several chunks for A, for A^T                                  */
+int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[12]);
 
 /* Copy one device array of the graph back to host memory (synchronises; tests/debugging).
  * which: 0 csr_ptr(int32,M+1) 1 csr_idx(int32,nnz) 2 csr_val(f32,nnz)

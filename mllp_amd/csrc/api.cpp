@@ -36,7 +36,7 @@ static int conv_forward(const mllp_graph* g, bool dst_is_var, int cin, const flo
     int rc;
     if ((rc = launch_param_prep(cp, cin, w.derived, s))) return rc;
     if (cin == 16 && (rc = launch_node_qp(x_dst, o.n_dst, w.derived, w.qp, w.t, s))) return rc;
-    return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, s);
+    return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, g->scratch, s);
 }
 
 // dh is overwritten with the ReLU-masked gradient; dx_* may be null; acc bit0 -> dx_dst, bit1 -> dx_src
@@ -47,8 +47,8 @@ static int conv_backward(const mllp_graph* g, bool dst_is_var, int cin, const fl
     const Orient& ot = dst_is_var ? g->A : g->At;      // source-major (rows = source nodes)
     int rc;
     if ((rc = launch_bwd_pre(o.n_dst, cin, cp, w, x_dst, h_out, dh, s))) return rc;
-    if ((rc = launch_attn_bwd_dst(o, cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, s))) return rc;
-    if (cin == 16 && dx_src && (rc = launch_attn_bwd_src(ot, w, x_src, dx_src, (acc >> 1) & 1, s))) return rc;
+    if ((rc = launch_attn_bwd_dst(o, cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, g->scratch, s))) return rc;
+    if (cin == 16 && dx_src && (rc = launch_attn_bwd_src(ot, w, x_src, dx_src, (acc >> 1) & 1, g->scratch, s))) return rc;
     if ((rc = launch_param_stats(cin, o.n_dst, w, x_dst, dh, s))) return rc;
     return launch_finalize_conv(cin, cp, w.stats, stat_blocks_for(o.n_dst), param_grads, s);
 }
@@ -133,7 +133,7 @@ using namespace mllp;
 
 extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream) {
     REQUIRE(g && d_H && d_Y, "null argument");
-    return launch_spmm(transpose ? g->At : g->A, d_H, d_Y, (hipStream_t)stream);
+    return launch_spmm(transpose ? g->At : g->A, d_H, d_Y, g->scratch, (hipStream_t)stream);
 }
 
 extern "C" int mllp_tconv_workspace_floats(const mllp_graph_t* g, int dst_is_var, int cin, int64_t* n_floats) {

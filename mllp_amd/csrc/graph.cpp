@@ -37,33 +37,50 @@ static int upload(mllp_graph* g, const T* host, size_t count, T** dev) {
     return MLLP_OK;
 }
 
-static void choose_tiers(int64_t nnz, int32_t& tier_wave, int32_t& tier_block) {
-    // Few rows (real Netlib, ~1M nonzeros): a sweep is latency bound, so long rows are spread over
-    // many lanes early.  Many rows (synthetic, 5e8 nonzeros): throughput bound, 16 lanes per row keep
-    // every lane busy and need no cross-wave merge.
-    bool throughput = nnz >= (int64_t)32 << 20;
-    if (tier_wave <= 0) tier_wave = throughput ? 1024 : 96;
-    if (tier_block <= 0) tier_block = throughput ? 16384 : 768;
-    if (tier_block < tier_wave) tier_block = tier_wave;
+static void choose_tiers(mllp_graph* g) {
+    // Few rows (real Netlib, ~1M nonzeros): a sweep is latency bound, so long rows are spread over many
+    // lanes early and very long rows over several workgroups; every work item then loops <= ~4 times.
+    // Many rows (synthetic, 5e8 nonzeros): throughput bound, 16 lanes per row keep every lane busy and
+    // need no cross-wave merge.
+    const bool throughput = g->nnz >= (int64_t)32 << 20;
+    if (g->tier_wave <= 0) g->tier_wave = throughput ? 1024 : 64;
+    if (g->tier_block <= 0) g->tier_block = throughput ? 16384 : 256;
+    if (g->tier_block < g->tier_wave) g->tier_block = g->tier_wave;
+    g->chunk_nnz = 4 * g->tier_block;
 }
 
 static int build_tiers(mllp_graph* g, Orient& o, const int* h_ptr) {
-    std::vector<int> rg, rw, rb;
+    std::vector<int> rg, rw, ck, sp;
+    int slots = 0;
     for (int r = 0; r < o.n_dst; ++r) {
-        int deg = h_ptr[r + 1] - h_ptr[r];
-        if (deg > g->tier_block) rb.push_back(r);
-        else if (deg > g->tier_wave) rw.push_back(r);
+        const int beg = h_ptr[r], end = h_ptr[r + 1], deg = end - beg;
+        if (deg > g->tier_block) {
+            const int nck = (deg + g->chunk_nnz - 1) / g->chunk_nnz;
+            if (nck == 1) {
+                ck.insert(ck.end(), {r, beg, end, -1});
+            } else {
+                sp.insert(sp.end(), {r, slots, nck, 0});
+                const int per = ((deg + nck - 1) / nck + 255) & ~255;   // equal shares, whole 256-nonzero passes
+                for (int c = 0; c < nck; ++c) {
+                    const int cb = std::min(beg + c * per, end), ce = std::min(cb + per, end);
+                    ck.insert(ck.end(), {r, cb, ce, slots++});   // an empty tail chunk merges as a neutral state
+                }
+            }
+        } else if (deg > g->tier_wave) rw.push_back(r);
         else rg.push_back(r);
     }
     o.n_group = (int)rg.size();
     o.n_wave = (int)rw.size();
-    o.n_block = (int)rb.size();
+    o.n_chunk = (int)(ck.size() / 4);
+    o.n_split = (int)(sp.size() / 4);
+    o.n_slots = slots;
     int rc;
-    if (o.n_wave == 0 && o.n_block == 0) {
+    if (o.n_wave == 0 && o.n_chunk == 0) {
         o.rows_group = nullptr;  // identity
     } else if ((rc = upload(g, rg.data(), rg.size(), &o.rows_group))) return rc;
     if ((rc = upload(g, rw.data(), rw.size(), &o.rows_wave))) return rc;
-    if ((rc = upload(g, rb.data(), rb.size(), &o.rows_block))) return rc;
+    if ((rc = upload(g, ck.data(), ck.size(), &o.chunks))) return rc;
+    if ((rc = upload(g, sp.data(), sp.size(), &o.split))) return rc;
     return MLLP_OK;
 }
 
@@ -82,6 +99,13 @@ static int finish_common(mllp_graph* g) {
         ipm[k] = (int)g->h_inst_ptr_m[k];
     }
     int rc;
+    {
+        const size_t slots = (size_t)std::max(std::max(g->A.n_slots, g->At.n_slots), 1);
+        void* p = nullptr;
+        MLLP_HIP_TRY(hipMalloc(&p, slots * SCRATCH_NS * sizeof(float)));
+        g->allocs.push_back(p);
+        g->scratch = static_cast<float*>(p);
+    }
     if ((rc = upload(g, inv_n.data(), inv_n.size(), &g->inv_n))) return rc;
     if ((rc = upload(g, ipn.data(), ipn.size(), &g->inst_ptr_n))) return rc;
     if ((rc = upload(g, ipm.data(), ipm.size(), &g->inst_ptr_m))) return rc;
@@ -174,7 +198,7 @@ extern "C" int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, con
     g->h_inst_ptr_n = pn;
     g->tier_wave = tier_wave;
     g->tier_block = tier_block;
-    choose_tiers(nnz, g->tier_wave, g->tier_block);
+    choose_tiers(g);
     g->A.n_dst = (int)M; g->A.n_src = (int)N;
     g->At.n_dst = (int)N; g->At.n_src = (int)M;
     int rc = MLLP_OK;
@@ -220,7 +244,7 @@ extern "C" int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_
     g->h_inst_ptr_n.assign(inst_ptr_n, inst_ptr_n + n_inst + 1);
     g->tier_wave = tier_wave;
     g->tier_block = tier_block;
-    choose_tiers(nnz, g->tier_wave, g->tier_block);
+    choose_tiers(g);
     g->A.n_dst = (int)M; g->A.n_src = (int)N;
     g->At.n_dst = (int)N; g->At.n_src = (int)M;
     auto dcopy = [&](const void* src, size_t bytes, void** dst) -> int {
@@ -269,11 +293,12 @@ extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     return MLLP_OK;
 }
 
-extern "C" int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[10]) {
+extern "C" int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[12]) {
     if (!g || !dims) return fail(MLLP_EINVAL, "mllp_graph_dims: null argument");
     dims[0] = g->M; dims[1] = g->N; dims[2] = g->nnz; dims[3] = g->n_inst;
-    dims[4] = g->A.n_group; dims[5] = g->A.n_wave; dims[6] = g->A.n_block;
-    dims[7] = g->At.n_group; dims[8] = g->At.n_wave; dims[9] = g->At.n_block;
+    dims[4] = g->A.n_group; dims[5] = g->A.n_wave; dims[6] = g->A.n_chunk;
+    dims[7] = g->At.n_group; dims[8] = g->At.n_wave; dims[9] = g->At.n_chunk;
+    dims[10] = g->A.n_split; dims[11] = g->At.n_split;
     return MLLP_OK;
 }
 

@@ -38,9 +38,11 @@ struct Orient {
     float* val = nullptr;  // [nnz] a_ij
     int* rows_group = nullptr;  // nullptr => identity (every row is in the group tier)
     int* rows_wave = nullptr;
-    int* rows_block = nullptr;
-    int n_group = 0, n_wave = 0, n_block = 0;
+    int* chunks = nullptr;      // [n_chunk] int4 {row, beg, end, slot}; slot < 0: the row's only chunk
+    int* split = nullptr;       // [n_split] int4 {row, first_slot, n_chunks, 0}: rows cut into several chunks
+    int n_group = 0, n_wave = 0, n_chunk = 0, n_split = 0, n_slots = 0;
 };
+constexpr int SCRATCH_NS = 20;  // floats per partial-state slot of a split row
 
 }  // namespace mllp
 
@@ -52,8 +54,9 @@ struct mllp_graph {
     int* inst_ptr_n = nullptr;   // [n_inst + 1] device
     int* inst_ptr_m = nullptr;   // [n_inst + 1] device
     std::vector<int64_t> h_inst_ptr_n, h_inst_ptr_m;
-    int tier_wave = 0, tier_block = 0;
+    int tier_wave = 0, tier_block = 0, chunk_nnz = 0;
     int max_inst_n = 0;
+    float* scratch = nullptr;    // partial states of split rows (sweeps on one graph must be stream-ordered)
     std::vector<void*> allocs;   // everything to hipFree on destroy
 };
 
@@ -106,17 +109,17 @@ int64_t conv_ws_floats(int64_t n_dst, int cin);
 ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
-int launch_spmm(const Orient& o, const float* H, float* Y, hipStream_t s);
+int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
 int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s);
 int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s);
 int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
-                    const float* x_dst, float* h_out, hipStream_t s);
+                    const float* x_dst, float* h_out, float* scratch, hipStream_t s);
 int launch_bwd_pre(int64_t n_dst, int cin, const float* conv_params, const ConvWs& w, const float* x_dst,
                    const float* h_out, float* dh, hipStream_t s);
 int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
-                        const float* g, float* dx_dst, int accumulate, hipStream_t s);
+                        const float* g, float* dx_dst, int accumulate, float* scratch, hipStream_t s);
 int launch_attn_bwd_src(const Orient& o_src_major, const ConvWs& w, const float* x_src, float* dx_src,
-                        int accumulate, hipStream_t s);
+                        int accumulate, float* scratch, hipStream_t s);
 int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_dst, const float* g, hipStream_t s);
 int launch_finalize_conv(int cin, const float* conv_params, const float* stats, int n_stat_blocks, float* grads,
                          hipStream_t s);

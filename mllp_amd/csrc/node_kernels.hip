@@ -190,7 +190,7 @@ int launch_bwd_pre(int64_t n_dst, int cin, const float* conv_params, const ConvW
 //           B[kk][q = lane & 15] = R[node0 + kk][q]  -- both are plain coalesced dword loads.
 // -------------------------------------------------------------------------------------------------
 int stat_blocks_for(int64_t n_dst) {
-    int64_t b = (n_dst + 255) / 256;
+    int64_t b = (n_dst + 1023) / 1024;
     if (b < 1) b = 1;
     if (b > STAT_BLOCKS_MAX) b = STAT_BLOCKS_MAX;
     return (int)b;
@@ -207,27 +207,36 @@ __global__ __launch_bounds__(BLOCK) void param_stats16_kernel(int n, const float
     f32x4 acc[STAT_TILES];
 #pragma unroll
     for (int i = 0; i < STAT_TILES; ++i) acc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const int nchunk = (n + 3) >> 2;
-    for (int ch = blockIdx.x * 4 + wave; ch < nchunk; ch += gridDim.x * 4) {
-        const int node = ch * 4 + kq;
-        float ag = 0.0f, adq = 0.0f, asc = 0.0f, bx = 0.0f, bz = 0.0f, be = 0.0f;
-        if (node < n) {
-            ag = g[(size_t)node * 16 + r];
-            adq = dqp[(size_t)node * 16 + r];
-            bx = x[(size_t)node * 16 + r];
-            bz = Z[(size_t)node * 16 + r];
-            const float2 sd = reinterpret_cast<const float2*>(dsdt)[node];
-            const float4 ax = reinterpret_cast<const float4*>(aux)[node];
-            asc = r == 0 ? sd.x : (r == 1 ? sd.y : 0.0f);
-            be = r == 0 ? 1.0f : (r == 1 ? ax.w : (r == 2 ? ax.x : 0.0f));
+    // a pass covers CH consecutive chunks of 4 nodes: all loads of the pass are issued before its MFMAs
+    constexpr int CH = 4;
+    const int npass = (n + 4 * CH - 1) / (4 * CH);
+    for (int ps = blockIdx.x * 4 + wave; ps < npass; ps += gridDim.x * 4) {
+        float ag[CH], adq[CH], asc[CH], bx[CH], bz[CH], be[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int node = (ps * CH + c) * 4 + kq;
+            ag[c] = adq[c] = asc[c] = bx[c] = bz[c] = be[c] = 0.0f;
+            if (node < n) {
+                ag[c] = g[(size_t)node * 16 + r];
+                adq[c] = dqp[(size_t)node * 16 + r];
+                bx[c] = x[(size_t)node * 16 + r];
+                bz[c] = Z[(size_t)node * 16 + r];
+                const float2 sd = reinterpret_cast<const float2*>(dsdt)[node];
+                const float4 ax = reinterpret_cast<const float4*>(aux)[node];
+                asc[c] = r == 0 ? sd.x : (r == 1 ? sd.y : 0.0f);
+                be[c] = r == 0 ? 1.0f : (r == 1 ? ax.w : (r == 2 ? ax.x : 0.0f));
+            }
         }
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, bx, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, bz, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, be, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq, bx, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq, be, acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc, bx, acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc, be, acc[6], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[c], bx[c], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[c], bz[c], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[c], be[c], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq[c], bx[c], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(adq[c], be[c], acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc[c], bx[c], acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc[c], be[c], acc[6], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int i = 0; i < STAT_TILES; ++i)
@@ -306,15 +315,27 @@ int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_d
 // finalize_conv: fixed-order sum of the per-workgroup partial tiles, then the small matrix algebra
 // (oracle/spmm_form.py::conv_bwd "grads = {...}").  One workgroup.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void finalize_conv_kernel(int cin, ConvParams p, const float* __restrict__ stats,
-                                                              int nblk, float* __restrict__ grads) {
+__global__ __launch_bounds__(1024) void finalize_conv_kernel(int cin, ConvParams p, const float* __restrict__ stats,
+                                                             int nblk, float* __restrict__ grads) {
+    __shared__ float P[4][STAT_FLOATS];
     __shared__ float T[STAT_FLOATS];
-    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK) {
-        float v = 0.0f;
-        for (int b = 0; b < nblk; ++b) v += stats[(size_t)b * STAT_FLOATS + i];
-        T[i] = v;
+    {
+        const int slice = threadIdx.x >> 8, col = threadIdx.x & 255;
+        float v[STAT_TILES];
+#pragma unroll
+        for (int i = 0; i < STAT_TILES; ++i) v[i] = 0.0f;
+        for (int b = slice; b < nblk; b += 4) {      // 7 independent loads per pass
+            const float* src = stats + (size_t)b * STAT_FLOATS + col;
+#pragma unroll
+            for (int i = 0; i < STAT_TILES; ++i) v[i] += src[i * 256];
+        }
+#pragma unroll
+        for (int i = 0; i < STAT_TILES; ++i) P[slice][i * 256 + col] = v[i];
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += 1024) T[i] = (P[0][i] + P[1][i]) + (P[2][i] + P[3][i]);
+    __syncthreads();
+    if (threadIdx.x >= BLOCK) return;
     const float* T0 = T; const float* T1 = T + 256; const float* T2 = T + 512; const float* T3 = T + 768;
     const float* T4 = T + 1024; const float* T5 = T + 1280; const float* T6 = T + 1536;
     float* gWk = grads;
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_conv_kernel(int cin, ConvParam
 
 int launch_finalize_conv(int cin, const float* conv_params, const float* stats, int n_stat_blocks, float* grads,
                          hipStream_t s) {
-    hipLaunchKernelGGL(finalize_conv_kernel, dim3(1), dim3(BLOCK), 0, s, cin, conv_params_at(conv_params, cin), stats,
+    hipLaunchKernelGGL(finalize_conv_kernel, dim3(1), dim3(1024), 0, s, cin, conv_params_at(conv_params, cin), stats,
                        n_stat_blocks, grads);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "finalize_conv");
@@ -367,7 +388,7 @@ int launch_finalize_conv(int cin, const float* conv_params, const float* stats, 
 // -------------------------------------------------------------------------------------------------
 constexpr int HEAD_BLOCKS_MAX = 1024;
 int head_blocks_for(int64_t n) {
-    int64_t b = (n + 15) / 16;
+    int64_t b = (n + 63) / 64;
     if (b < 1) b = 1;
     if (b > HEAD_BLOCKS_MAX) b = HEAD_BLOCKS_MAX;
     return (int)b;
@@ -417,14 +438,21 @@ __global__ __launch_bounds__(BLOCK) void head_kernel(int mode, int n, const floa
     }
 }
 
-__global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restrict__ partials, int nblk,
-                                                           float* __restrict__ grad_fc, float* __restrict__ loss) {
-    const int i = threadIdx.x;
-    if (i >= 18) return;
+__global__ __launch_bounds__(BLOCK) void head_finalize_kernel(const float* __restrict__ partials, int nblk,
+                                                              float* __restrict__ grad_fc, float* __restrict__ loss) {
+    __shared__ float sh[8][32];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
     float v = 0.0f;
-    for (int b = 0; b < nblk; ++b) v += partials[(size_t)b * 18 + i];
-    if (i < 17) grad_fc[i] = v;
-    else if (loss) loss[0] = v;
+    if (col < 18)
+        for (int b = slice; b < nblk; b += 8) v += partials[(size_t)b * 18 + col];
+    sh[slice][col] = v;
+    __syncthreads();
+    if (threadIdx.x < 18) {
+        float t = 0.0f;
+        for (int q = 0; q < 8; ++q) t += sh[q][threadIdx.x];
+        if (threadIdx.x < 17) grad_fc[threadIdx.x] = t;
+        else if (loss) loss[0] = t;
+    }
 }
 
 int launch_head(int mode, int64_t n, const float* h3v, const float* fc_w, const float* fc_b, const float* inv_n,
@@ -438,7 +466,7 @@ int launch_head(int mode, int64_t n, const float* h3v, const float* fc_w, const 
 }
 
 int launch_head_finalize(const float* partials, int n_blocks, float* grad_fc, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, partials, n_blocks, grad_fc, loss);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(BLOCK), 0, s, partials, n_blocks, grad_fc, loss);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "head_finalize");
 }
@@ -495,13 +523,15 @@ __device__ __forceinline__ unsigned orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(BLOCK) void topm_metrics_kernel(const int* __restrict__ ptr_n, const int* __restrict__ ptr_m,
-                                                             const float* __restrict__ logits,
-                                                             const float* __restrict__ labels, float* __restrict__ out) {
+constexpr int TOPM_T = 1024;
+__global__ __launch_bounds__(TOPM_T) void topm_metrics_kernel(const int* __restrict__ ptr_n, const int* __restrict__ ptr_m,
+                                                              const float* __restrict__ logits,
+                                                              const float* __restrict__ labels, float* __restrict__ out) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
-    __shared__ float s_red[BLOCK];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_red[4][TOPM_T / 64];
+    __shared__ unsigned s_cnt[TOPM_T / 64];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int beg = ptr_n[k], n = ptr_n[k + 1] - beg;
     int m = ptr_m[k + 1] - ptr_m[k];
     if (m > n) m = n;
@@ -515,10 +545,10 @@ __global__ __launch_bounds__(BLOCK) void topm_metrics_kernel(const int* __restri
     unsigned mask = 0u;
     for (int pass = 3; pass >= 0; --pass) {
         const int shift = pass * 8;
-        hist[tid] = 0u;
+        if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
-        for (int i = tid; i < n; i += BLOCK) {
+        for (int i = tid; i < n; i += TOPM_T) {
             const unsigned key = orderable(z[i]);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
@@ -538,34 +568,60 @@ __global__ __launch_bounds__(BLOCK) void topm_metrics_kernel(const int* __restri
     }
     const unsigned thr = s_prefix;
     const unsigned need_eq = s_need;   // how many keys equal to thr belong to the top-m (>= 1)
-    float tp = 0.0f, ysum = 0.0f, eqc = 0.0f, eqy = 0.0f;
-    for (int i = tid; i < n; i += BLOCK) {
+    float vals[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // tp (key > thr), sum y, count (key == thr), sum y (key == thr)
+    for (int i = tid; i < n; i += TOPM_T) {
         const unsigned key = orderable(z[i]);
         const float yi = y[i];
-        ysum += yi;
-        if (key > thr) tp += yi;
-        else if (key == thr) { eqc += 1.0f; eqy += yi; }
+        vals[1] += yi;
+        if (key > thr) vals[0] += yi;
+        else if (key == thr) { vals[2] += 1.0f; vals[3] += yi; }
     }
-    float vals[4] = {tp, ysum, eqc, eqy};
     float tot[4];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
-        s_red[tid] = vals[q];
-        __syncthreads();
-        for (int st = BLOCK / 2; st > 0; st >>= 1) {
-            if (tid < st) s_red[tid] += s_red[tid + st];
+        float v = vals[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[q][wave] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = 0.0f;
+        for (int w = 0; w < TOPM_T / 64; ++w) v += s_red[q][w];
+        tot[q] = v;
+    }
+    float TP = tot[0];
+    if ((unsigned)tot[2] == need_eq) {
+        TP += tot[3];
+    } else {
+        // tie at the threshold: the first need_eq equal keys in INDEX order belong to the top-m
+        // (ordered block scan with wave ballots; identical columns make this common on real LPs)
+        unsigned running = 0u;
+        float tie = 0.0f;
+        for (int base = 0; base < n && running < need_eq; base += TOPM_T) {
+            const int i = base + tid;
+            const bool f = i < n && orderable(z[i]) == thr;
+            const unsigned long long bal = __ballot(f);
+            const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
             __syncthreads();
+            if (lane == 0) s_cnt[wave] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned off = 0u, total = 0u;
+            for (int w = 0; w < TOPM_T / 64; ++w) {
+                const unsigned c = s_cnt[w];
+                if (w < wave) off += c;
+                total += c;
+            }
+            if (f && running + off + before < need_eq) tie += y[i];
+            running += total;
         }
-        tot[q] = s_red[0];
+        for (int o = 32; o > 0; o >>= 1) tie += __shfl_xor(tie, o, 64);
         __syncthreads();
+        if (lane == 0) s_red[0][wave] = tie;
+        __syncthreads();
+        for (int w = 0; w < TOPM_T / 64; ++w) TP += s_red[0][w];
     }
     if (tid == 0) {
-        float TP = tot[0];
-        if ((unsigned)tot[2] == need_eq) TP += tot[3];
-        else {   // rare: tie at the threshold, take the first need_eq in index order
-            unsigned taken = 0;
-            for (int i = 0; i < n && taken < need_eq; ++i)
-                if (orderable(z[i]) == thr) { TP += y[i]; ++taken; }
-        }
         const float FP = (float)m - TP, FN = tot[1] - TP;
         const float den = 2.0f * TP + FP + FN;
         out[2 * k] = TP;
@@ -577,7 +633,7 @@ int launch_topm_metrics(const mllp_graph* g, const float* logits, const float* l
                         hipStream_t s) {
     (void)scratch;
     if (g->n_inst == 0) return MLLP_OK;
-    hipLaunchKernelGGL(topm_metrics_kernel, dim3((unsigned)g->n_inst), dim3(BLOCK), 0, s, g->inst_ptr_n, g->inst_ptr_m,
+    hipLaunchKernelGGL(topm_metrics_kernel, dim3((unsigned)g->n_inst), dim3(TOPM_T), 0, s, g->inst_ptr_n, g->inst_ptr_m,
                        logits, labels, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "topm_metrics");

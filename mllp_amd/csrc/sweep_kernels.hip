@@ -9,13 +9,19 @@
 // (reference call sites linear_program_methods.py:241-247, PyG
 // TransformerConv.message / utils.softmax restated in oracle/pyg_restatement.py.)
 //
-// Mapping: one LANE per nonzero.  A lane streams (idx, val) coalesced, gathers the whole 64-byte
-// source row X_j with four 16-byte loads, does the dot products and accumulations in its own
-// registers, and only the per-row totals cross lanes (DPP all-reduce inside the 16-lane row, then
-// the LDS crossbar for a 64-lane wave, then LDS for a workgroup).  Rows are tiered by length:
-//   group tier  : 16 lanes per row, 4 rows per wavefront (short rows / throughput regime)
-//   wave tier   : 64 lanes per row
-//   block tier  : 256 threads per row, four per-wave partial states merged through LDS
+// Mapping (16-channel sweeps): one QUAD of lanes per nonzero, lane `part` = 0..3 owning channels
+// 4*part .. 4*part+3.  The four lanes of a quad read the four 16-byte pieces of ONE 64-byte source row,
+// so a wave-wide gather instruction touches 16 rows as 16 whole 64-byte segments (the vector memory
+// pipeline looks up one line per quad instead of one per lane: the first version, one lane per nonzero
+// with four dwordx4 loads each, ran the gathers at ~10 B/clk/CU).  Dot products are 4 FMAs + a 2-step
+// DPP quad reduction; accumulators are 4 floats per lane; per-row totals are combined over the quads of
+// the row's lane group with DPP row rotations.  Scalar (layer-1) sweeps keep one lane per nonzero.
+// Rows are tiered by length so that no work item loops more than a few times in the latency-bound
+// regime (real Netlib) while the throughput regime (synthetic) keeps 16 lanes per row:
+//   group tier : 16 lanes (4 quads) per row, 4 rows per wavefront
+//   wave tier  : 64 lanes (16 quads) per row
+//   chunk tier : 256 threads per chunk of a row; a row longer than the chunk size is split over several
+//                workgroups whose partial states go to a scratch buffer and are merged by combine_kernel
 // Tiles of the group tier are remapped so that each XCD walks a contiguous row range: the source
 // rows gathered by neighbouring tiles then come out of one XCD's L2.
 #include "device_utils.h"
@@ -29,15 +35,18 @@ struct OrientDev {
     const float* __restrict__ val;
     const int* __restrict__ rows_group;
     const int* __restrict__ rows_wave;
-    const int* __restrict__ rows_block;
-    int n_group, n_wave, n_block, nbA, nbB;
+    const int4* __restrict__ chunks;   // {row, beg, end, slot}; slot < 0: the row's only chunk
+    const int4* __restrict__ split;    // {row, first_slot, n_chunks, 0}
+    int n_group, n_wave, n_chunk, n_split, nbA, nbB;
 };
 
 static OrientDev make_dev(const Orient& o) {
     OrientDev d;
     d.ptr = o.ptr; d.idx = o.idx; d.val = o.val;
-    d.rows_group = o.rows_group; d.rows_wave = o.rows_wave; d.rows_block = o.rows_block;
-    d.n_group = o.n_group; d.n_wave = o.n_wave; d.n_block = o.n_block;
+    d.rows_group = o.rows_group; d.rows_wave = o.rows_wave;
+    d.chunks = reinterpret_cast<const int4*>(o.chunks);
+    d.split = reinterpret_cast<const int4*>(o.split);
+    d.n_group = o.n_group; d.n_wave = o.n_wave; d.n_chunk = o.n_chunk; d.n_split = o.n_split;
     d.nbA = (o.n_group + 15) / 16;
     d.nbB = (o.n_wave + 3) / 4;
     return d;
@@ -45,16 +54,17 @@ static OrientDev make_dev(const Orient& o) {
 
 // -------------------------------------------------------------------------------------------------
 // generic tiered driver.  Op provides:
-//   Args                         kernel arguments (POD)
-//   NS                           floats of per-wave state exchanged through LDS in the block tier
-//   load_row(args,row,deg)       per-row inputs (uniform over the lanes of the row)
-//   edges<G,U>(args,o,beg,end,first,stride,gl)   accumulate this lane's nonzeros
-//   reduce<G>()                  all-reduce the state over the G lanes
-//   to_lds(float*) / merge_from_lds(const float*, nwaves)
-//   epilogue(args,row,deg,gl)    called with gl in [0,16) on lanes holding the reduced state
+//   Args, NS (floats of exchanged state), LPN (lanes per nonzero: 4 or 1)
+//   load_row(args,row,deg,gl)   per-row inputs
+//   edges<G,U>(args,o,beg,end,first,stride,gl)   accumulate this lane's nonzeros; one pass of a G-lane
+//                               group covers (G / LPN) * U nonzeros
+//   reduce<G>()                 all-reduce the state over the G lanes of the row
+//   to_mem(float*)              lanes 0..3 of a reduced group write the state
+//   merge_from(const float*, n) rebuild the state from n stored states (LDS or global)
+//   epilogue(args,row,deg,gl)   gl in [0,16): write the row's outputs
 // -------------------------------------------------------------------------------------------------
 template <class Op, int UA, int UB>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, OrientDev o) {
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, OrientDev o, float* __restrict__ scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
     if (b < o.nbA) {
@@ -64,8 +74,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, Or
             const int row = o.rows_group ? o.rows_group[slot] : slot;
             const int beg = o.ptr[row], end = o.ptr[row + 1];
             Op op;
-            op.load_row(args, row, end - beg);
-            op.template edges<16, UA>(args, o, beg, end, 0, 16 * UA, lane & 15);
+            op.load_row(args, row, end - beg, lane & 15);
+            op.template edges<16, UA>(args, o, beg, end, 0, (16 / Op::LPN) * UA, lane & 15);
             op.template reduce<16>();
             op.epilogue(args, row, end - beg, lane & 15);
         }
@@ -75,35 +85,120 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, Or
             const int row = o.rows_wave[slot];
             const int beg = o.ptr[row], end = o.ptr[row + 1];
             Op op;
-            op.load_row(args, row, end - beg);
-            op.template edges<64, UB>(args, o, beg, end, 0, 64 * UB, lane);
+            op.load_row(args, row, end - beg, lane);
+            op.template edges<64, UB>(args, o, beg, end, 0, (64 / Op::LPN) * UB, lane);
             op.template reduce<64>();
             if (lane < 16) op.epilogue(args, row, end - beg, lane);
         }
     } else {
         __shared__ float sh[4 * Op::NS];
-        const int row = o.rows_block[b - o.nbA - o.nbB];
-        const int beg = o.ptr[row], end = o.ptr[row + 1];
+        const int4 ck = o.chunks[b - o.nbA - o.nbB];
+        const int row = ck.x, beg = ck.y, end = ck.z;
+        constexpr int PER = (64 / Op::LPN) * UB;   // nonzeros per wave and pass
         Op op;
-        op.load_row(args, row, end - beg);
-        op.template edges<64, UB>(args, o, beg, end, wave * 64 * UB, 4 * 64 * UB, lane);
+        op.load_row(args, row, end - beg, lane);
+        op.template edges<64, UB>(args, o, beg, end, wave * PER, 4 * PER, lane);
         op.template reduce<64>();
-        if (lane == 0) op.to_lds(sh + wave * Op::NS);
+        if (lane < 4) op.to_mem(sh + wave * Op::NS);
         __syncthreads();
         if (wave == 0) {
-            op.merge_from_lds(sh, 4);
-            if (lane < 16) op.epilogue(args, row, end - beg, lane);
+            op.merge_from(sh, 4);
+            if (ck.w < 0) {
+                if (lane < 16) op.epilogue(args, row, o.ptr[row + 1] - o.ptr[row], lane);
+            } else if (lane < 4) {
+                op.to_mem(scratch + (size_t)ck.w * Op::NS);
+            }
         }
     }
 }
 
-// load U (idx,val) pairs for this lane; invalid slots get idx 0 / val 0 and ok = false
-template <int G, int U>
+// rows that were split over several chunk workgroups: merge their partial states in chunk order
+template <class Op>
+__global__ __launch_bounds__(BLOCK) void combine_kernel(typename Op::Args args, OrientDev o,
+                                                        const float* __restrict__ scratch) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= o.n_split) return;
+    const int4 sp = o.split[i];
+    const int gl = threadIdx.x & 15;
+    const int deg = o.ptr[sp.x + 1] - o.ptr[sp.x];
+    Op op;
+    op.load_row(args, sp.x, deg, gl);
+    op.merge_from(scratch + (size_t)sp.y * Op::NS, sp.z);
+    op.epilogue(args, sp.x, deg, gl);
+}
+
+// all-reduce over the quads of a G-lane group, for values that are replicated or owned per `part`
+// (lanes 4 apart hold the same channel): G = 16 -> rotate by 8 and 4 inside the DPP row
+template <int G>
+__device__ __forceinline__ float quads_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    if (G == 64) {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float quads_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    if (G == 64) {
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+    }
+    return v;
+}
+// sum over the 4 lanes of a quad (every lane gets the total)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+// value held by lane J of the own quad
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return dpp_mov<J * 0x55>(v);   // quad_perm [J,J,J,J]
+}
+// all 16 channels from the 4 per-part float4 of a quad
+__device__ __forceinline__ void quad_allgather(const float4& v, float (&r)[16]) {
+    r[0] = quad_bcast<0>(v.x);  r[1] = quad_bcast<0>(v.y);  r[2] = quad_bcast<0>(v.z);  r[3] = quad_bcast<0>(v.w);
+    r[4] = quad_bcast<1>(v.x);  r[5] = quad_bcast<1>(v.y);  r[6] = quad_bcast<1>(v.z);  r[7] = quad_bcast<1>(v.w);
+    r[8] = quad_bcast<2>(v.x);  r[9] = quad_bcast<2>(v.y);  r[10] = quad_bcast<2>(v.z); r[11] = quad_bcast<2>(v.w);
+    r[12] = quad_bcast<3>(v.x); r[13] = quad_bcast<3>(v.y); r[14] = quad_bcast<3>(v.z); r[15] = quad_bcast<3>(v.w);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ void fma4(float s, const float4& x, float4& acc) {
+    acc.x = fmaf(s, x.x, acc.x);
+    acc.y = fmaf(s, x.y, acc.y);
+    acc.z = fmaf(s, x.z, acc.z);
+    acc.w = fmaf(s, x.w, acc.w);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// exp(x) for x <= ~0 with ~1-2 ulp: hardware 2^t (v_exp_f32) on t = x*log2(e), with the rounding error
+// of that product (and of the constant) fed back as a first-order correction.  The plain
+// v_exp_f32(x * log2e) loses |x| * 6e-8 relative accuracy, too much against the 1e-5 parity budget.
+__device__ __forceinline__ float exp_acc(float x) {
+    const float L2E_HI = 1.44269502163e+00f, L2E_LO = 1.92596299112e-08f, LN2 = 0.693147180560f;
+    x = fmaxf(x, -150.0f);   // exp(-150) is exactly 0 in fp32; keeps NEG_BIG sentinels away from inf - inf
+    const float t = x * L2E_HI;
+    float r = fmaf(x, L2E_HI, -t);
+    r = fmaf(x, L2E_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * LN2, e);
+}
+
+// load U (idx,val) pairs for this lane's nonzero slots; invalid slots get idx 0 / val 0 and ok = false
+template <int G, int U, int LPN>
 __device__ __forceinline__ void load_edges(const OrientDev& o, int e0, int end, int gl, int (&col)[U], float (&a)[U],
                                            bool (&ok)[U]) {
+    const int q = (LPN == 4) ? (gl >> 2) : gl;
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-        const int e = e0 + k * G + gl;
+        const int e = e0 + k * (G / LPN) + q;
         ok[k] = e < end;
         col[k] = ok[k] ? o.idx[e] : 0;
         a[k] = ok[k] ? o.val[e] : 0.0f;
@@ -118,12 +213,13 @@ struct SpmmOp {
         const float* __restrict__ X;
         float* __restrict__ Y;
     };
-    static constexpr int NS = 16;
-    float acc[16];
+    static constexpr int NS = 16, LPN = 4;
+    float4 acc;
+    int part;
 
-    __device__ __forceinline__ void load_row(const Args&, int, int) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    __device__ __forceinline__ void load_row(const Args&, int, int, int gl) {
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        part = gl & 3;
     }
     template <int G, int U>
     __device__ __forceinline__ void edges(const Args& args, const OrientDev& o, int beg, int end, int first, int stride,
@@ -132,35 +228,32 @@ struct SpmmOp {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
-            float x[U][16];
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
+            float4 x[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) load_row16(args.X + (size_t)col[k] * 16, x[k]);
+            for (int k = 0; k < U; ++k) x[k] = ld4(args.X + (size_t)col[k] * 16 + 4 * part);
 #pragma unroll
-            for (int k = 0; k < U; ++k)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(a[k], x[k][c], acc[c]);
+            for (int k = 0; k < U; ++k) fma4(a[k], x[k], acc);
         }
     }
     template <int G>
     __device__ __forceinline__ void reduce() {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = group_sum<G>(acc[c]);
+        acc.x = quads_sum<G>(acc.x);
+        acc.y = quads_sum<G>(acc.y);
+        acc.z = quads_sum<G>(acc.z);
+        acc.w = quads_sum<G>(acc.w);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s[c] = acc[c];
-    }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float v = 0.0f;
-            for (int w = 0; w < nw; ++w) v += s[w * NS + c];
-            acc[c] = v;
+    __device__ __forceinline__ void to_mem(float* s) const { *reinterpret_cast<float4*>(s + 4 * part) = acc; }
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < n; ++w) {
+            const float4 t = ld4(s + w * NS + 4 * part);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
+        acc = v;
     }
     __device__ __forceinline__ void epilogue(const Args& args, int row, int, int gl) {
-        args.Y[(size_t)row * 16 + gl] = select16(acc, gl);
+        if (gl < 4) *reinterpret_cast<float4*>(args.Y + (size_t)row * 16 + 4 * gl) = acc;
     }
 };
 
@@ -181,18 +274,19 @@ struct FwdArgs {
 
 struct Fwd16Op {
     using Args = FwdArgs;
-    static constexpr int NS = 19;
-    float qp[16], t;
-    float m, L, u, Z[16];
+    static constexpr int NS = 20, LPN = 4;   // {m, L, u, -, Z[16]}
+    float4 qp, Z;
+    float t, m, L, u;
+    int part;
 
-    __device__ __forceinline__ void load_row(const Args& args, int row, int) {
-        load_row16(args.qp + (size_t)row * 16, qp);
+    __device__ __forceinline__ void load_row(const Args& args, int row, int, int gl) {
+        part = gl & 3;
+        qp = ld4(args.qp + (size_t)row * 16 + 4 * part);
         t = args.t[row];
         m = NEG_BIG;
         L = 0.0f;
         u = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Z[c] = 0.0f;
+        Z = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     template <int G, int U>
     __device__ __forceinline__ void edges(const Args& args, const OrientDev& o, int beg, int end, int first, int stride,
@@ -201,105 +295,95 @@ struct Fwd16Op {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
-            float x[U][16];
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
+            float4 x[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) load_row16(args.X + (size_t)col[k] * 16, x[k]);
+            for (int k = 0; k < U; ++k) x[k] = ld4(args.X + (size_t)col[k] * 16 + 4 * part);
             float l[U], mi = NEG_BIG;
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const float d = dot16(qp, x[k], a[k] * t);
+                const float d = fmaf(a[k], t, quad_sum(dot4(qp, x[k])));
                 l[k] = ok[k] ? d : NEG_BIG;
                 mi = fmaxf(mi, l[k]);
             }
-            mi = group_max<G>(mi);                 // uniform over the lanes of the row
+            mi = quads_max<G>(mi);                 // uniform over the lanes of the row
             const float m_new = fmaxf(m, mi);
-            const float scale = expf(m - m_new);   // 0 on the first pass (m = NEG_BIG), 1 when the max holds
-            if (__any(scale != 1.0f)) {            // wave-uniform branch: rescale only when some row's max moved
-                L *= scale;
-                u *= scale;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) Z[c] *= scale;
-            }
+            const float scale = exp_acc(m - m_new);   // 0 on the first pass (m = NEG_BIG), 1 when the max holds
+            L *= scale;
+            u *= scale;
+            Z.x *= scale; Z.y *= scale; Z.z *= scale; Z.w *= scale;
             m = m_new;
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const float p = expf(l[k] - m_new);  // invalid slots: exp(-huge) == 0
+                const float p = exp_acc(l[k] - m_new);  // invalid slots: exp(-huge) == 0
                 L += p;
                 u = fmaf(p, a[k], u);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) Z[c] = fmaf(p, x[k][c], Z[c]);
+                fma4(p, x[k], Z);
             }
         }
     }
     template <int G>
     __device__ __forceinline__ void reduce() {
-        // a lane that saw no nonzero still holds m = NEG_BIG with zero sums; inside one row every lane
-        // shares m by construction (group_max), so plain sums are correct
-        m = group_max<G>(m);
-        L = group_sum<G>(L);
-        u = group_sum<G>(u);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Z[c] = group_sum<G>(Z[c]);
+        // every lane of the row shares m (quads_max); L and u are replicated inside a quad, Z is owned per part:
+        // summing over the quads (lanes 4 apart) is the row total for all of them
+        L = quads_sum<G>(L);
+        u = quads_sum<G>(u);
+        Z.x = quads_sum<G>(Z.x);
+        Z.y = quads_sum<G>(Z.y);
+        Z.z = quads_sum<G>(Z.z);
+        Z.w = quads_sum<G>(Z.w);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-        s[0] = m; s[1] = L; s[2] = u;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s[3 + c] = Z[c];
+    __device__ __forceinline__ void to_mem(float* s) const {
+        if (part == 0) *reinterpret_cast<float4*>(s) = make_float4(m, L, u, 0.0f);
+        *reinterpret_cast<float4*>(s + 4 + 4 * part) = Z;
     }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
         float M = NEG_BIG;
-        for (int w = 0; w < nw; ++w) M = fmaxf(M, s[w * NS]);
-        float l = 0.0f, uu = 0.0f, z[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) z[c] = 0.0f;
-        for (int w = 0; w < nw; ++w) {
-            const float f = expf(s[w * NS] - M);   // waves without nonzeros: exp(-huge) == 0
-            l = fmaf(f, s[w * NS + 1], l);
-            uu = fmaf(f, s[w * NS + 2], uu);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) z[c] = fmaf(f, s[w * NS + 3 + c], z[c]);
+        for (int w = 0; w < n; ++w) M = fmaxf(M, s[w * NS]);
+        float l = 0.0f, uu = 0.0f;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < n; ++w) {
+            const float4 h0 = ld4(s + w * NS);
+            const float f = exp_acc(h0.x - M);       // states without nonzeros: exp(-huge) == 0
+            l = fmaf(f, h0.y, l);
+            uu = fmaf(f, h0.z, uu);
+            fma4(f, ld4(s + w * NS + 4 + 4 * part), z);
         }
-        m = M; L = l; u = uu;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Z[c] = z[c];
+        m = M; L = l; u = uu; Z = z;
     }
     // lane gl = output channel
     __device__ __forceinline__ void epilogue(const Args& args, int row, int deg, int gl) {
         const float rinv = 1.0f / (L + 1e-16f);   // torch_geometric.utils.softmax: sum + 1e-16
         const float S = L * rinv;
         const float un = u * rinv;
-        float zn[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) zn[c] = Z[c] * rinv;
-        float xr[16], wv[16], ws[16];
+        const float4 zn = make_float4(Z.x * rinv, Z.y * rinv, Z.z * rinv, Z.w * rinv);
+        float za[16], xr[16], wv[16], ws[16];
+        quad_allgather(zn, za);
         load_row16(args.xd + (size_t)row * 16, xr);
         load_row16(args.p.Wv + gl * 16, wv);
         load_row16(args.p.Ws + gl * 16, ws);
         float o = args.p.bs[gl];
         o = fmaf(S, args.p.bv[gl], o);
         o = fmaf(un, args.p.we[gl], o);
-        o = dot16(wv, zn, o);
+        o = dot16(wv, za, o);
         o = dot16(ws, xr, o);
         args.h[(size_t)row * 16 + gl] = fmaxf(o, 0.0f);
-        args.Z[(size_t)row * 16 + gl] = select16(zn, gl);
-        if (gl == 0) {
-            float4 ax = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);
-            reinterpret_cast<float4*>(args.aux)[row] = ax;
-        }
+        if (gl < 4) *reinterpret_cast<float4*>(args.Z + (size_t)row * 16 + 4 * gl) = zn;
+        if (gl == 0) reinterpret_cast<float4*>(args.aux)[row] = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);
     }
 };
 
 // =================================================================================================
-// attention forward, 1 source channel (layer 1: scalar node features, reference methods.py:90-91)
+// attention forward, 1 source channel (layer 1: scalar node features, reference methods.py:90-91):
+// one lane per nonzero
 // =================================================================================================
 struct Fwd1Op {
     using Args = FwdArgs;
-    static constexpr int NS = 4;
+    static constexpr int NS = 4, LPN = 1;
     float qp, t;
     float m, L, u, Z;
 
-    __device__ __forceinline__ void load_row(const Args& args, int row, int) {
+    __device__ __forceinline__ void load_row(const Args& args, int row, int, int) {
         const float* D = args.derived;
         const float x = args.xd[row];
         qp = fmaf(D[OFF_PQ], x, D[OFF_PQ0]);
@@ -316,7 +400,7 @@ struct Fwd1Op {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
             float x[U], l[U], mi = NEG_BIG;
 #pragma unroll
             for (int k = 0; k < U; ++k) x[k] = args.X[col[k]];
@@ -328,14 +412,14 @@ struct Fwd1Op {
             }
             mi = group_max<G>(mi);
             const float m_new = fmaxf(m, mi);
-            const float scale = expf(m - m_new);
+            const float scale = exp_acc(m - m_new);
             L *= scale;
             u *= scale;
             Z *= scale;
             m = m_new;
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const float p = expf(l[k] - m_new);
+                const float p = exp_acc(l[k] - m_new);
                 L += p;
                 u = fmaf(p, a[k], u);
                 Z = fmaf(p, x[k], Z);
@@ -344,23 +428,23 @@ struct Fwd1Op {
     }
     template <int G>
     __device__ __forceinline__ void reduce() {
-        m = group_max<G>(m);
         L = group_sum<G>(L);
         u = group_sum<G>(u);
         Z = group_sum<G>(Z);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-        s[0] = m; s[1] = L; s[2] = u; s[3] = Z;
+    __device__ __forceinline__ void to_mem(float* s) const {
+        *reinterpret_cast<float4*>(s) = make_float4(m, L, u, Z);   // lanes 0..3 write the same value
     }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
         float M = NEG_BIG;
-        for (int w = 0; w < nw; ++w) M = fmaxf(M, s[w * NS]);
+        for (int w = 0; w < n; ++w) M = fmaxf(M, s[w * NS]);
         float l = 0.0f, uu = 0.0f, z = 0.0f;
-        for (int w = 0; w < nw; ++w) {
-            const float f = expf(s[w * NS] - M);
-            l = fmaf(f, s[w * NS + 1], l);
-            uu = fmaf(f, s[w * NS + 2], uu);
-            z = fmaf(f, s[w * NS + 3], z);
+        for (int w = 0; w < n; ++w) {
+            const float4 h0 = ld4(s + w * NS);
+            const float f = exp_acc(h0.x - M);
+            l = fmaf(f, h0.y, l);
+            uu = fmaf(f, h0.z, uu);
+            z = fmaf(f, h0.w, z);
         }
         m = M; L = l; u = uu; Z = z;
     }
@@ -376,8 +460,7 @@ struct Fwd1Op {
         args.h[(size_t)row * 16 + gl] = fmaxf(o, 0.0f);
         if (gl == 0) {
             args.Z[row] = zn;
-            float4 ax = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);
-            reinterpret_cast<float4*>(args.aux)[row] = ax;
+            reinterpret_cast<float4*>(args.aux)[row] = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);
         }
     }
 };
@@ -400,21 +483,22 @@ struct BwdDstArgs {
 
 struct BwdDst16Op {
     using Args = BwdDstArgs;
-    static constexpr int NS = 18;
-    float qp[16], gv[16], t, m, rinv, ge, cc;
-    float dqp[16], ds, dt;
+    static constexpr int NS = 20, LPN = 4;   // {ds, dt, -, -, dqp[16]}
+    float4 qp, gv, dqp;
+    float t, m, rinv, ge, cc, ds, dt;
+    int part;
 
-    __device__ __forceinline__ void load_row(const Args& args, int row, int) {
+    __device__ __forceinline__ void load_row(const Args& args, int row, int, int gl) {
+        part = gl & 3;
         const float* r = args.rec + (size_t)row * REC_W;
-        load_row16(r, qp);
-        load_row16(r + 16, gv);
-        const float4 s0 = reinterpret_cast<const float4*>(r + 32)[0];
-        const float4 s1 = reinterpret_cast<const float4*>(r + 32)[1];
-        t = s0.x; m = s0.y; rinv = s0.z; ge = s0.w; cc = s1.x;
+        qp = ld4(r + 4 * part);
+        gv = ld4(r + 16 + 4 * part);
+        const float4 s0 = ld4(r + 32);
+        t = s0.x; m = s0.y; rinv = s0.z; ge = s0.w;
+        cc = r[36];
         ds = 0.0f;
         dt = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dqp[c] = 0.0f;
+        dqp = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     template <int G, int U>
     __device__ __forceinline__ void edges(const Args& args, const OrientDev& o, int beg, int end, int first, int stride,
@@ -423,62 +507,60 @@ struct BwdDst16Op {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
-            float x[U][16];
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
+            float4 x[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) load_row16(args.X + (size_t)col[k] * 16, x[k]);
+            for (int k = 0; k < U; ++k) x[k] = ld4(args.X + (size_t)col[k] * 16 + 4 * part);
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const float l = dot16(qp, x[k], a[k] * t);
-                const float alpha = ok[k] ? expf(l - m) * rinv : 0.0f;
-                const float dl = alpha * dot16(gv, x[k], fmaf(a[k], ge, cc));
+                const float l = fmaf(a[k], t, quad_sum(dot4(qp, x[k])));
+                const float alpha = ok[k] ? exp_acc(l - m) * rinv : 0.0f;
+                const float dl = alpha * (quad_sum(dot4(gv, x[k])) + fmaf(a[k], ge, cc));
                 ds += dl;
                 dt = fmaf(dl, a[k], dt);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) dqp[c] = fmaf(dl, x[k][c], dqp[c]);
+                fma4(dl, x[k], dqp);
             }
         }
     }
     template <int G>
     __device__ __forceinline__ void reduce() {
-        ds = group_sum<G>(ds);
-        dt = group_sum<G>(dt);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dqp[c] = group_sum<G>(dqp[c]);
+        ds = quads_sum<G>(ds);
+        dt = quads_sum<G>(dt);
+        dqp.x = quads_sum<G>(dqp.x);
+        dqp.y = quads_sum<G>(dqp.y);
+        dqp.z = quads_sum<G>(dqp.z);
+        dqp.w = quads_sum<G>(dqp.w);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-        s[0] = ds; s[1] = dt;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s[2 + c] = dqp[c];
+    __device__ __forceinline__ void to_mem(float* s) const {
+        if (part == 0) *reinterpret_cast<float4*>(s) = make_float4(ds, dt, 0.0f, 0.0f);
+        *reinterpret_cast<float4*>(s + 4 + 4 * part) = dqp;
     }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
-        float a = 0.0f, b = 0.0f, z[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) z[c] = 0.0f;
-        for (int w = 0; w < nw; ++w) {
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
+        float a = 0.0f, b = 0.0f;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < n; ++w) {
             a += s[w * NS];
             b += s[w * NS + 1];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) z[c] += s[w * NS + 2 + c];
+            const float4 v = ld4(s + w * NS + 4 + 4 * part);
+            z.x += v.x; z.y += v.y; z.z += v.z; z.w += v.w;
         }
-        ds = a; dt = b;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dqp[c] = z[c];
+        ds = a; dt = b; dqp = z;
     }
     // dx_i = Ws^T g_i + Pq^T dq'_i + ds_i Pb + dt_i Pt        (lane gl = input channel)
     __device__ __forceinline__ void epilogue(const Args& args, int row, int, int gl) {
-        args.dqp[(size_t)row * 16 + gl] = select16(dqp, gl);
+        if (gl < 4) *reinterpret_cast<float4*>(args.dqp + (size_t)row * 16 + 4 * gl) = dqp;
         if (gl == 0) reinterpret_cast<float2*>(args.dsdt)[row] = make_float2(ds, dt);
         if (args.dx_dst) {
             const float* D = args.derived;
-            float gr[16], wsT[16], pqT[16];
+            float da[16], gr[16], wsT[16], pqT[16];
+            quad_allgather(dqp, da);
             load_row16(args.g + (size_t)row * 16, gr);
             load_row16(D + OFF_WST + gl * 16, wsT);   // WsT[gl][o] = Ws[o][gl]
             load_row16(D + OFF_PQT + gl * 16, pqT);   // PqT[gl][k] = Pq[k][gl]
             float v = ds * D[OFF_PB + gl];
             v = fmaf(dt, D[OFF_PT + gl], v);
             v = dot16(wsT, gr, v);
-            v = dot16(pqT, dqp, v);
+            v = dot16(pqT, da, v);
             float* dst = args.dx_dst + (size_t)row * 16 + gl;
             *dst = args.accumulate ? *dst + v : v;
         }
@@ -489,13 +571,13 @@ struct BwdDst16Op {
 //   rec8_i = { q'_i, gv_i, t_i, rowmax_i, rinv_i, ge_i, c_i, 0 }
 struct BwdDst1Op {
     using Args = BwdDstArgs;
-    static constexpr int NS = 3;
+    static constexpr int NS = 4, LPN = 1;
     float qp, gv, t, m, rinv, ge, cc;
     float dqp, ds, dt;
 
-    __device__ __forceinline__ void load_row(const Args& args, int row, int) {
-        const float4 s0 = reinterpret_cast<const float4*>(args.rec + (size_t)row * 8)[0];
-        const float4 s1 = reinterpret_cast<const float4*>(args.rec + (size_t)row * 8)[1];
+    __device__ __forceinline__ void load_row(const Args& args, int row, int, int) {
+        const float4 s0 = ld4(args.rec + (size_t)row * 8);
+        const float4 s1 = ld4(args.rec + (size_t)row * 8 + 4);
         qp = s0.x; gv = s0.y; t = s0.z; m = s0.w;
         rinv = s1.x; ge = s1.y; cc = s1.z;
         dqp = 0.0f; ds = 0.0f; dt = 0.0f;
@@ -507,14 +589,14 @@ struct BwdDst1Op {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
             float x[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) x[k] = args.X[col[k]];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const float l = fmaf(qp, x[k], a[k] * t);
-                const float alpha = ok[k] ? expf(l - m) * rinv : 0.0f;
+                const float alpha = ok[k] ? exp_acc(l - m) * rinv : 0.0f;
                 const float dl = alpha * fmaf(gv, x[k], fmaf(a[k], ge, cc));
                 ds += dl;
                 dt = fmaf(dl, a[k], dt);
@@ -528,15 +610,14 @@ struct BwdDst1Op {
         dt = group_sum<G>(dt);
         dqp = group_sum<G>(dqp);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-        s[0] = ds; s[1] = dt; s[2] = dqp;
+    __device__ __forceinline__ void to_mem(float* s) const {
+        *reinterpret_cast<float4*>(s) = make_float4(ds, dt, dqp, 0.0f);
     }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
         float a = 0.0f, b = 0.0f, c = 0.0f;
-        for (int w = 0; w < nw; ++w) {
-            a += s[w * NS];
-            b += s[w * NS + 1];
-            c += s[w * NS + 2];
+        for (int w = 0; w < n; ++w) {
+            const float4 v = ld4(s + w * NS);
+            a += v.x; b += v.y; c += v.z;
         }
         ds = a; dt = b; dqp = c;
     }
@@ -561,13 +642,14 @@ struct BwdSrcArgs {
 
 struct BwdSrc16Op {
     using Args = BwdSrcArgs;
-    static constexpr int NS = 16;
-    float xj[16], acc[16];
+    static constexpr int NS = 16, LPN = 4;
+    float4 xj, acc;
+    int part;
 
-    __device__ __forceinline__ void load_row(const Args& args, int row, int) {
-        load_row16(args.X + (size_t)row * 16, xj);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    __device__ __forceinline__ void load_row(const Args& args, int row, int, int gl) {
+        part = gl & 3;
+        xj = ld4(args.X + (size_t)row * 16 + 4 * part);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     template <int G, int U>
     __device__ __forceinline__ void edges(const Args& args, const OrientDev& o, int beg, int end, int first, int stride,
@@ -576,44 +658,53 @@ struct BwdSrc16Op {
             int col[U];
             float a[U];
             bool ok[U];
-            load_edges<G, U>(o, e0, end, gl, col, a, ok);
+            load_edges<G, U, LPN>(o, e0, end, gl, col, a, ok);
+            float4 qp[U], gv[U], s0[U];
+            float cc[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const float* r = args.rec + (size_t)col[k] * REC_W;
-                float qp[16], gv[16];
-                load_row16(r, qp);
-                load_row16(r + 16, gv);
-                const float4 s0 = reinterpret_cast<const float4*>(r + 32)[0];
-                const float cc = r[36];
-                const float l = dot16(qp, xj, a[k] * s0.x);
-                const float alpha = ok[k] ? expf(l - s0.y) * s0.z : 0.0f;
-                const float dl = alpha * dot16(gv, xj, fmaf(a[k], s0.w, cc));
+                qp[k] = ld4(r + 4 * part);
+                gv[k] = ld4(r + 16 + 4 * part);
+                s0[k] = ld4(r + 32);        // {t, rowmax, rinv, ge}
+                cc[k] = r[36];
+            }
 #pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(alpha, gv[c], fmaf(dl, qp[c], acc[c]));
+            for (int k = 0; k < U; ++k) {
+                const float l = fmaf(a[k], s0[k].x, quad_sum(dot4(qp[k], xj)));
+                const float alpha = ok[k] ? exp_acc(l - s0[k].y) * s0[k].z : 0.0f;
+                const float dl = alpha * (quad_sum(dot4(gv[k], xj)) + fmaf(a[k], s0[k].w, cc[k]));
+                fma4(alpha, gv[k], acc);
+                fma4(dl, qp[k], acc);
             }
         }
     }
     template <int G>
     __device__ __forceinline__ void reduce() {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = group_sum<G>(acc[c]);
+        acc.x = quads_sum<G>(acc.x);
+        acc.y = quads_sum<G>(acc.y);
+        acc.z = quads_sum<G>(acc.z);
+        acc.w = quads_sum<G>(acc.w);
     }
-    __device__ __forceinline__ void to_lds(float* s) const {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s[c] = acc[c];
-    }
-    __device__ __forceinline__ void merge_from_lds(const float* s, int nw) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float v = 0.0f;
-            for (int w = 0; w < nw; ++w) v += s[w * NS + c];
-            acc[c] = v;
+    __device__ __forceinline__ void to_mem(float* s) const { *reinterpret_cast<float4*>(s + 4 * part) = acc; }
+    __device__ __forceinline__ void merge_from(const float* s, int n) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < n; ++w) {
+            const float4 t = ld4(s + w * NS + 4 * part);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
+        acc = v;
     }
     __device__ __forceinline__ void epilogue(const Args& args, int row, int, int gl) {
-        float* dst = args.dX + (size_t)row * 16 + gl;
-        const float v = select16(acc, gl);
-        *dst = args.accumulate ? *dst + v : v;
+        if (gl < 4) {
+            float4* dst = reinterpret_cast<float4*>(args.dX + (size_t)row * 16 + 4 * gl);
+            float4 v = acc;
+            if (args.accumulate) {
+                const float4 old = *dst;
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            *dst = v;
+        }
     }
 };
 
@@ -621,47 +712,55 @@ struct BwdSrc16Op {
 // launchers
 // -------------------------------------------------------------------------------------------------
 template <class Op, int UA, int UB>
-static int launch_sweep(const Orient& o, const typename Op::Args& args, hipStream_t s, const char* name) {
+static int launch_sweep(const Orient& o, const typename Op::Args& args, float* scratch, hipStream_t s,
+                        const char* name) {
+    static_assert(Op::NS <= SCRATCH_NS, "scratch slot too small");
     OrientDev d = make_dev(o);
-    const int64_t blocks = (int64_t)d.nbA + d.nbB + d.n_block;
+    const int64_t blocks = (int64_t)d.nbA + d.nbB + d.n_chunk;
     if (blocks == 0) return MLLP_OK;
     if (blocks >= INT32_MAX) return fail(MLLP_ERANGE, "too many workgroups");
-    hipLaunchKernelGGL((sweep_kernel<Op, UA, UB>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args, d);
+    hipLaunchKernelGGL((sweep_kernel<Op, UA, UB>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args, d, scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, name);
+    if (d.n_split > 0) {
+        hipLaunchKernelGGL((combine_kernel<Op>), dim3((unsigned)((d.n_split + 15) / 16)), dim3(BLOCK), 0, s, args, d,
+                           scratch);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, name);
+    }
     return MLLP_OK;
 }
 
-int launch_spmm(const Orient& o, const float* H, float* Y, hipStream_t s) {
+int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s) {
     SpmmOp::Args a{H, Y};
-    return launch_sweep<SpmmOp, 2, 2>(o, a, s, "spmm_csr");
+    return launch_sweep<SpmmOp, 4, 4>(o, a, scratch, s, "spmm_csr");
 }
 
 int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
-                    const float* x_dst, float* h_out, hipStream_t s) {
+                    const float* x_dst, float* h_out, float* scratch, hipStream_t s) {
     FwdArgs a;
     a.X = x_src; a.xd = x_dst; a.qp = w.qp; a.t = w.t; a.derived = w.derived;
     a.p = conv_params_at(conv_params, cin);
     a.h = h_out; a.Z = w.Z; a.aux = w.aux;
-    if (cin == 16) return launch_sweep<Fwd16Op, 2, 2>(o, a, s, "attn_fwd16");
-    return launch_sweep<Fwd1Op, 2, 2>(o, a, s, "attn_fwd1");
+    if (cin == 16) return launch_sweep<Fwd16Op, 4, 4>(o, a, scratch, s, "attn_fwd16");
+    return launch_sweep<Fwd1Op, 2, 2>(o, a, scratch, s, "attn_fwd1");
 }
 
 int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,
-                        const float* g, float* dx_dst, int accumulate, hipStream_t s) {
+                        const float* g, float* dx_dst, int accumulate, float* scratch, hipStream_t s) {
     (void)conv_params;
     BwdDstArgs a;
     a.X = x_src; a.rec = w.rec; a.g = g; a.derived = w.derived;
     a.dqp = w.dqp; a.dsdt = w.dsdt; a.dx_dst = dx_dst; a.accumulate = accumulate;
-    if (cin == 16) return launch_sweep<BwdDst16Op, 2, 2>(o, a, s, "attn_bwd_dst16");
+    if (cin == 16) return launch_sweep<BwdDst16Op, 4, 4>(o, a, scratch, s, "attn_bwd_dst16");
     a.dx_dst = nullptr;
-    return launch_sweep<BwdDst1Op, 2, 2>(o, a, s, "attn_bwd_dst1");
+    return launch_sweep<BwdDst1Op, 2, 2>(o, a, scratch, s, "attn_bwd_dst1");
 }
 
 int launch_attn_bwd_src(const Orient& o_src_major, const ConvWs& w, const float* x_src, float* dx_src, int accumulate,
-                        hipStream_t s) {
+                        float* scratch, hipStream_t s) {
     BwdSrcArgs a{x_src, w.rec, dx_src, accumulate};
-    return launch_sweep<BwdSrc16Op, 1, 1>(o_src_major, a, s, "attn_bwd_src16");
+    return launch_sweep<BwdSrc16Op, 2, 2>(o_src_major, a, scratch, s, "attn_bwd_src16");
 }
 
 }  // namespace mllp

@@ -87,9 +87,10 @@ class LPBatch:
 
     # ---- introspection -----------------------------------------------------------------------
     def dims(self):
-        d = (c_int64 * 10)()
+        d = (c_int64 * 12)()
         _lib.check(_lib.lib().mllp_graph_dims(self._h, d))
-        keys = ["M", "N", "nnz", "n_inst", "A_group", "A_wave", "A_block", "At_group", "At_wave", "At_block"]
+        keys = ["M", "N", "nnz", "n_inst", "A_group", "A_wave", "A_block", "At_group", "At_wave", "At_block",
+                "A_split", "At_split"]
         return dict(zip(keys, [int(v) for v in d]))
 
     def export(self, which):

@@ -216,6 +216,7 @@ def test_full_netlib_batch(LPBatch, weights):
     b = LPBatch.from_instances(inst)
     d = b.dims()
     assert d["nnz"] == 1074147 and d["A_wave"] > 0 and d["A_block"] > 0 and d["At_block"] > 0   # all tiers in play
+    assert d["A_split"] > 0 and d["At_split"] > 0                                                 # incl. rows split over workgroups
     loss, logits, grads = b.loss_step(flat_gpu)
     close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "logits")
     close(loss.cpu().numpy(), [r["loss"]], RTOL_ACT, "loss")

@@ -1,0 +1,150 @@
+"""Training driver with the CLI, outputs and loop semantics of the reference's
+`linear_program_experiment.py` for the sparse bipartite methods ('gs-topk', 'soft-topk').
+
+    python linear_program_experiment.py --cfg linear_program_netlib.yaml
+
+reference linear_program_experiment.py:17-46 (config, seed, dataset, criterion), :115-157 (loop:
+graph -> forward -> BCEWithLogitsLoss -> backward -> Adam step -> top-m F1 / correct count ->
+print / train_log.json), :176-177 (torch.save(state_dict) to linear_program_<data>_<method>.pt).
+
+What differs, by design: the graph of an instance is built once and stays in HBM (the reference
+rebuilds it in Python every step, :124); forward/BCE/backward/Adam/metrics run in libmllp_hip.so;
+`batch_size` (optional yaml key) > 1 groups instances into block-diagonal batches with ONE Adam step
+per batch; with WORLD_SIZE > 1 (torchrun) each batch is sharded over the ranks and the flat gradient is
+all-reduced over RCCL.  `batch_size: 1` on one GPU reproduces the reference's update sequence.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .config import load_config
+from .data import LPInstance, get_netlib_dataset
+from .model import GNNModel, set_seed
+
+SPARSE_METHODS = ("gs-topk", "soft-topk")
+
+
+def _dist_setup():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return dist.get_rank(), world
+    return 0, 1
+
+
+def train_method(cfg, method_name, train_dataset, train_dict, out=print):
+    from .graph import LPBatch
+    from .trainer import LPTrainer, shard_instances
+    rank, world = _dist_setup()
+    model_path = f"linear_program_{cfg.train_data_type}_{method_name}.pt"
+    ckpt_path = f"linear_program_{cfg.train_data_type}_{method_name}.ckpt"
+    out(f"Training the model weights for {method_name}...")
+    device = torch.device(cfg.get_default("device"))
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("this build runs the learned-LP path on MI355X through HIP only (device: 'cuda'); "
+                           "there is no CPU fallback")
+    model = GNNModel().to(device)                     # reference :117
+    if world > 1:                                     # same initial weights on every rank
+        import torch.distributed as dist
+        flat0 = model.flat_parameters().detach().clone()
+        dist.broadcast(flat0, src=0)
+        model.load_flat(flat0)
+    instances = [LPInstance.from_reference_tuple(t) for t in train_dataset]
+    bs = int(cfg.get_default("batch_size"))
+    if bs <= 0:
+        bs = len(instances)
+    groups = [list(range(i, min(i + bs, len(instances)))) for i in range(0, len(instances), bs)]
+    batches = []                                       # (global instance ids of this rank, LPBatch or None, global count)
+    for grp in groups:
+        mine = grp if world == 1 else [grp[j] for j in shard_instances([instances[i].nnz for i in grp], world)[rank]]
+        b = LPBatch.from_instances([instances[i] for i in mine]) if mine else None
+        batches.append((mine, b, len(grp)))
+    trainer = LPTrainer(model.flat_parameters().detach(), lr=cfg.train_lr,
+                        use_hip_graph=bool(cfg.get_default("use_hip_graph")), with_metrics=True)
+    start_epoch = 0
+    if cfg.get_default("resume") and os.path.exists(ckpt_path):
+        ck = torch.load(ckpt_path, map_location=device, weights_only=True)
+        trainer.params.copy_(ck["params"])
+        trainer.opt.load_state_dict(ck["opt"])
+        start_epoch = int(ck["epoch"]) + 1
+        train_dict.update({k: list(v) for k, v in json.loads(ck["train_dict"]).items()})
+        out(f"resumed from {ckpt_path} at epoch {start_epoch}")
+    log_every = max(int(cfg.get_default("log_every")), 1)
+    save_every = int(cfg.get_default("save_every"))
+
+    def save_all(epoch):
+        if rank != 0:
+            return
+        model.load_flat(trainer.params)
+        torch.save(model.state_dict(), model_path)                                   # reference :176
+        torch.save({"params": trainer.params, "opt": trainer.opt.state_dict(), "epoch": epoch,
+                    "train_dict": json.dumps(train_dict)}, ckpt_path)
+
+    for epoch in range(start_epoch, cfg.train_iter):                                # reference :120
+        obj_sum = torch.zeros(1, device=device)
+        pending = []
+        for mine, b, gcount in batches:
+            if b is None:      # a rank without instances in this batch still joins the all-reduce
+                trainer.step_empty()
+                continue
+            trainer.global_instances = gcount
+            loss, _ = trainer.step(b)                                               # reference :124-144
+            obj_sum += loss * gcount        # loss is the batch mean over gcount instances (this rank's share)
+            if epoch % log_every == 0:
+                pending.append((mine, trainer._plans[id(b)]["metrics"].clone()))
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(obj_sum)
+        for mine, met in pending:                                                   # reference :146-153
+            met = met.cpu().numpy()
+            for j, gi in enumerate(mine):
+                inst = instances[gi]
+                correct_num, f1 = float(met[j, 0]), float(met[j, 1])
+                out("%8d, %8d, %8d, %5f" % (correct_num, inst.m, inst.n, f1))
+                train_dict[inst.name].append(correct_num)
+        obj = float(obj_sum[0]) / len(instances)
+        train_dict["obj"].append(obj)                  # plain float: the reference's numpy.float32 breaks json.dump
+        if rank == 0:
+            with open("train_log.json", "w") as json_file:                          # reference :155-156
+                json.dump(train_dict, json_file)
+        out(f"epoch {epoch}, obj={obj}")                                            # reference :157
+        if save_every and (epoch + 1) % save_every == 0:
+            save_all(epoch)
+    save_all(cfg.train_iter - 1)
+    out(f"Model saved to {model_path}.")
+    return model_path
+
+
+def main(argv=None):
+    cfg = load_config(argv)                                                         # reference :17
+    set_seed()                                                                      # reference :19
+    if cfg.train_data_type == "netlib":                                             # reference :28-35
+        names = cfg.get_default("instances")
+        if cfg.methods[0] in ("invariant", "angleNet"):
+            raise NotImplementedError(
+                f"method {cfg.methods[0]!r} is the reference's dense research path (AngleModel / InvariantModel, "
+                "reference linear_program_methods.py:136-200); this build implements the sparse bipartite "
+                f"GNNModel path: use one of {SPARSE_METHODS}")
+        train_dataset, train_dict = get_netlib_dataset(normalize=True, names=names)
+    else:
+        raise ValueError(f"Unknown training dataset {cfg.train_data_type}!")
+    for method_name in cfg.methods:                                                 # reference :45
+        if method_name in SPARSE_METHODS:
+            train_method(cfg, method_name, train_dataset, train_dict)
+        else:
+            raise NotImplementedError(f"method {method_name!r} is outside the sparse bipartite hot path of this "
+                                      f"build (supported: {SPARSE_METHODS})")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

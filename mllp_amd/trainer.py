@@ -129,6 +129,14 @@ class LPTrainer:
     def _opt(self, p):
         self.opt.step(p["grads"])
 
+    def step_empty(self):
+        """A rank that owns no instance of the current batch: contribute a zero gradient and apply the same Adam."""
+        if not hasattr(self, "_zero"):
+            self._zero = torch.zeros(NUM_PARAMS, device=self.params.device)
+        self._zero.zero_()
+        allreduce_sum_(self._zero)
+        self.opt.step(self._zero)
+
     def step(self, batch: LPBatch):
         """One optimizer step on `batch`; returns (loss, logits) device tensors (valid until the next step)."""
         import torch.distributed as dist

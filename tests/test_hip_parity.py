@@ -315,3 +315,41 @@ def test_synthetic_device_batch_matches_host_build(LPBatch):
     loss, logits, grads = sb.loss_step(o1.flatten_state(sd).float().cuda())
     close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "synthetic logits")
     close(grads.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "synthetic grads")
+
+
+def test_experiment_driver_end_to_end(tmp_path, monkeypatch, golden):
+    """python linear_program_experiment.py --cfg <yaml> with batch_size 1: the update sequence is the
+    reference's (one Adam step per instance, experiment.py:123-144); outputs: train_log.json, .pt state_dict."""
+    import json
+    from mllp_amd import experiment
+    from mllp_amd.model import GNNModel
+    names = ["afiro.mps", "sc50a.mps", "kb2.mps"]
+    y = tmp_path / "cfg.yaml"
+    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 2\nmethods:\n  - 'gs-topk'\n"
+                 f"instances: {names}\nbatch_size: 1\nuse_hip_graph: True\n")
+    monkeypatch.chdir(tmp_path)
+    # the driver seeds torch (set_seed) and builds GNNModel(): capture those initial weights for the oracle
+    experiment.set_seed()
+    init = GNNModel().flat_parameters().detach().double()
+    lines = []
+    monkeypatch.setattr("builtins.print", lambda *a, **k: lines.append(" ".join(str(x) for x in a)))
+    assert experiment.main(["--cfg", str(y)]) == 0
+    monkeypatch.undo()
+    log = json.load(open(tmp_path / "train_log.json"))
+    assert set(log) == {"obj", "afiro.mps", "kb2.mps", "sc50a.mps"} and len(log["obj"]) == 2
+    sd = torch.load(tmp_path / "linear_program_netlib_gs-topk.pt", weights_only=True)
+    assert list(sd.keys()) == [k for k, _ in o1.state_dict_spec()]
+    # oracle: same loop in fp64 (sorted instance order), metrics by torch.topk
+    inst = load_packed(sorted(names))
+    tr = o1.ReferenceTrainer(o1.unflatten_state(init), lr=1e-3, dtype=torch.float64, rebuild_graph=False)
+    for epoch in range(2):
+        objs = []
+        for i in inst:
+            loss, z = tr.step(i)
+            objs.append(loss)
+        np.testing.assert_allclose(log["obj"][epoch], np.mean(objs), rtol=2e-5)
+    got = torch.cat([v.reshape(-1) for v in sd.values()]).cpu().numpy()
+    keep = grad_mask()
+    np.testing.assert_allclose(got[keep], o1.flatten_state(tr.sd).detach().numpy()[keep], rtol=2e-4, atol=3e-6)
+    assert any(l.startswith("epoch 1, obj=") for l in lines) and any("Model saved to" in l for l in lines)
+    assert sum(1 for l in lines if l.count(",") == 3) == 6          # one metrics line per instance and epoch

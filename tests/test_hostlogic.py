@@ -189,3 +189,23 @@ def test_data_parallel_world2_equals_single_process(tmp_path, subset5):
             keep[off:off + c] = False
         off += c
     np.testing.assert_allclose(got["params"][keep], params[keep], rtol=1e-5, atol=1e-7)
+
+
+def test_root_shims_and_driver_argument_errors(tmp_path, monkeypatch):
+    import config as root_config
+    import linear_program_data as root_data
+    import linear_program_methods as root_methods
+    from mllp_amd import experiment
+    assert root_config.load_config is cfgmod.load_config and root_data.get_netlib_dataset is datamod.get_netlib_dataset
+    assert root_methods.GNNModel.__name__ == "GNNModel"
+    with pytest.raises(NotImplementedError):
+        root_methods.AngleModel
+    with pytest.raises(ValueError, match="Please specify path to the configuration file!"):
+        experiment.main([])
+    y = tmp_path / "angle.yaml"
+    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'angleNet'\n")
+    with pytest.raises(NotImplementedError, match="angleNet"):
+        experiment.main(["--cfg", str(y)])
+    y.write_text("train_data_type: 'twitch'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'gs-topk'\n")
+    with pytest.raises(ValueError, match="Unknown training dataset"):
+        experiment.main(["--cfg", str(y)])

@@ -97,6 +97,25 @@ int mllp_graph_export(const mllp_graph_t* g, int which, void* host_dst, int64_t 
  * ---------------------------------------------------------------------------------------------- */
 int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream);
 
+/* Optional LDS-tiled copy of one orientation for large batches (rows of ~100+ nonzeros): the nonzeros
+ * re-blocked into row tiles x column blocks so that source rows are read from LDS instead of L2.
+ *   mllp_tiled_geometry: rows per tile, source nodes per column block, and the number of entries of one
+ *     (tile, block) segment that fit the kernel's LDS window (longer segments take several windows).
+ *   d_tile_blk [n_tiles+1]  first (tile, block) index of each row tile (a tile lists the contiguous
+ *                           range of column blocks it touches)
+ *   d_blk_id   [n_tb]       global column-block id of each (tile, block)
+ *   d_ptr2     [n_tb * rows_per_tile + 1]  entry offsets: inside a (tile, block) the rows are ordered by their
+ *                           number of entries in that block, descending (position k = k-th longest)
+ *   d_perm     [n_tb * rows_per_tile]      row (inside its tile) of every sorted position
+ *   d_ent      [nnz][2]     {column id inside its block, fp32 value bits}, ordered by (tile, block, position, column)
+ * The arrays are BORROWED: the caller keeps them alive while attached (n_tiles = 0 detaches).
+ * With a tiled copy attached mllp_spmm_csr_f32 uses it for that orientation.                       */
+int mllp_tiled_geometry(int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity);
+int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int64_t n_tiles, int64_t n_tb,
+                            int32_t max_blocks_per_tile /* largest tile_blk[t+1]-tile_blk[t]; at most 255 */,
+                            const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
+                            const int32_t* d_perm, const int32_t* d_ent);
+
 /* ------------------------------------------------------------------------------------------------
  * One torch_geometric.nn.TransformerConv((cin, cin), 16, edge_dim=1) followed by ReLU, as called at
  * linear_program_methods.py:241-247 (construction :206-211).  dst_is_var = 1 for the *_w2s convs

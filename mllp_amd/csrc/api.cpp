@@ -136,6 +136,37 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
     return launch_spmm(transpose ? g->At : g->A, d_H, d_Y, g->scratch, (hipStream_t)stream);
 }
 
+extern "C" int mllp_tiled_geometry(int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity) {
+    REQUIRE(rows_per_tile && cols_per_block && bundle_capacity, "null argument");
+    int a, b, c;
+    tiled_geometry(&a, &b, &c);
+    *rows_per_tile = a; *cols_per_block = b; *bundle_capacity = c;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int64_t n_tiles, int64_t n_tb,
+                                       int32_t max_blocks_per_tile,
+                                       const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
+                                       const int32_t* d_perm, const int32_t* d_ent) {
+    REQUIRE(g, "null graph");
+    Orient& o = transpose ? g->At : g->A;
+    if (n_tiles == 0) {   // detach
+        o.tiled = Tiled();
+        return MLLP_OK;
+    }
+    REQUIRE(d_tile_blk && d_blk_id && d_ptr2 && d_perm && d_ent, "null array");
+    int R, CB, CAP;
+    tiled_geometry(&R, &CB, &CAP);
+    REQUIRE(n_tiles == (o.n_dst + R - 1) / R, "n_tiles must be ceil(rows / rows_per_tile)");
+    REQUIRE(n_tb > 0 && n_tb * (int64_t)R < INT32_MAX, "bad (tile, block) count");
+    REQUIRE(max_blocks_per_tile > 0 && max_blocks_per_tile <= tiled_max_blocks_per_tile(),
+            "a row tile touches more column blocks than the kernel's table holds");
+    o.tiled.n_tiles = (int)n_tiles; o.tiled.n_tb = (int)n_tb;
+    o.tiled.tile_blk = d_tile_blk; o.tiled.blk_id = d_blk_id; o.tiled.ptr2 = d_ptr2; o.tiled.perm = d_perm;
+    o.tiled.ent = d_ent;
+    return MLLP_OK;
+}
+
 extern "C" int mllp_tconv_workspace_floats(const mllp_graph_t* g, int dst_is_var, int cin, int64_t* n_floats) {
     REQUIRE(g && n_floats, "null argument");
     REQUIRE(cin == 1 || cin == 16, "cin must be 1 or 16");

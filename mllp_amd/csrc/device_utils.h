@@ -94,6 +94,17 @@ __device__ __forceinline__ float dot16(const float (&a)[16], const float (&b)[16
     return s;
 }
 
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ void fma4(float s, const float4& x, float4& acc) {
+    acc.x = fmaf(s, x.x, acc.x);
+    acc.y = fmaf(s, x.y, acc.y);
+    acc.z = fmaf(s, x.z, acc.z);
+    acc.w = fmaf(s, x.w, acc.w);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
 // XCD-aware, bijective block -> tile remap (guide T1): blocks b and b+8 share an XCD (and its L2),
 // so give each XCD a contiguous range of tiles; consecutive tiles then gather the same source rows
 // from one L2.  Valid for any number of tiles.

@@ -31,7 +31,18 @@ int hip_fail(hipError_t e, const char* what);
 // rows) or of A^T (dst = variable columns).  Rows are split in three tiers by nonzero count:
 //   group tier: 16 lanes per row (4 rows per wavefront), wave tier: 64 lanes per row,
 //   block tier: one 256-thread workgroup per row.
+// optional LDS-tiled copy of an orientation (tiled_kernels.hip); arrays are borrowed from the caller
+struct Tiled {
+    int n_tiles = 0, n_tb = 0;
+    const int* tile_blk = nullptr;   // [n_tiles + 1]
+    const int* blk_id = nullptr;     // [n_tb]
+    const int* ptr2 = nullptr;       // [n_tb * rows_per_tile + 1] offsets of the length-sorted positions
+    const int* perm = nullptr;       // [n_tb * rows_per_tile] row of each sorted position
+    const int* ent = nullptr;        // [nnz][2] {col_local, value bits}
+};
+
 struct Orient {
+    Tiled tiled;
     int n_dst = 0, n_src = 0;
     int* ptr = nullptr;    // [n_dst + 1]
     int* idx = nullptr;    // [nnz] source ids
@@ -110,6 +121,9 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
+int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
+int tiled_geometry(int* rows_per_tile, int* cols_per_block, int* bundle_capacity);
+int tiled_max_blocks_per_tile();
 int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s);
 int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s);
 int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,

@@ -167,16 +167,6 @@ __device__ __forceinline__ void quad_allgather(const float4& v, float (&r)[16]) 
     r[8] = quad_bcast<2>(v.x);  r[9] = quad_bcast<2>(v.y);  r[10] = quad_bcast<2>(v.z); r[11] = quad_bcast<2>(v.w);
     r[12] = quad_bcast<3>(v.x); r[13] = quad_bcast<3>(v.y); r[14] = quad_bcast<3>(v.z); r[15] = quad_bcast<3>(v.w);
 }
-__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
-    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
-}
-__device__ __forceinline__ void fma4(float s, const float4& x, float4& acc) {
-    acc.x = fmaf(s, x.x, acc.x);
-    acc.y = fmaf(s, x.y, acc.y);
-    acc.z = fmaf(s, x.z, acc.z);
-    acc.w = fmaf(s, x.w, acc.w);
-}
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // exp(x) for x <= ~0 with ~1-2 ulp: hardware 2^t (v_exp_f32) on t = x*log2(e), with the rounding error
 // of that product (and of the constant) fed back as a first-order correction.  The plain
@@ -732,6 +722,7 @@ static int launch_sweep(const Orient& o, const typename Op::Args& args, float* s
 }
 
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s) {
+    if (o.tiled.n_tiles > 0) return launch_spmm_tiled(o.tiled, o.n_dst, o.n_src, H, Y, s);
     SpmmOp::Args a{H, Y};
     return launch_sweep<SpmmOp, 4, 4>(o, a, scratch, s, "spmm_csr");
 }

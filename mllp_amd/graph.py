@@ -77,6 +77,89 @@ class LPBatch:
         torch.cuda.synchronize()
         return LPBatch(h, M, N, nnz, len(inst_m), inst_m, inst_n, x1, x2, labels, names)
 
+    # ---- LDS-tiled copies (throughput regime) -----------------------------------------------------
+    def _device_orientation(self, transpose):
+        """(ptr, idx, val) of one orientation as cuda tensors (downloaded from the graph once)."""
+        base = 3 if transpose else 0
+        dev = self.x1.device
+        return (torch.from_numpy(self.export(base)).to(dev), torch.from_numpy(self.export(base + 1)).to(dev),
+                torch.from_numpy(self.export(base + 2)).to(dev))
+
+    def enable_tiled(self, transpose=False, arrays=None):
+        """Build and attach the LDS-tiled copy of A (transpose=False) or A^T.  Returns a dict with the
+        geometry, or None when the matrix does not qualify (index range).
+        Re-blocking is done once with torch ops on the device (plumbing, not the hot path)."""
+        L = _lib.lib()
+        R, CB, CAP = c_int32(), c_int32(), c_int32()
+        _lib.check(L.mllp_tiled_geometry(ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
+        R, CB, CAP = R.value, CB.value, CAP.value
+        ptr, idx, val = arrays if arrays is not None else self._device_orientation(transpose)
+        n_dst = self.N if transpose else self.M
+        dev, nnz = idx.device, int(idx.numel())
+        if nnz == 0:
+            return None
+        n_tiles = (n_dst + R - 1) // R
+        deg = (ptr[1:] - ptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(n_dst, device=dev, dtype=torch.int32), deg)
+        tile = torch.div(rows, R, rounding_mode="floor")
+        blk = torch.div(idx, CB, rounding_mode="floor")
+        tl = tile.long()
+        lo = torch.full((n_tiles,), 2 ** 30, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amin")
+        hi = torch.full((n_tiles,), -1, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amax")
+        nbt = torch.where(hi >= 0, hi - lo + 1, torch.zeros_like(hi)).long()
+        lo = torch.where(hi >= 0, lo, torch.zeros_like(lo))
+        tile_blk = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
+        tile_blk[1:] = torch.cumsum(nbt, 0)
+        n_tb = int(tile_blk[-1])
+        max_nbt = int(nbt.max())
+        if n_tb * R >= 2 ** 31 - 1 or max_nbt > 255:
+            return None
+        key = (tile_blk[tl] + (blk - lo[tl]).long()) * R + (rows - tile * R).long()
+        del rows, tile, tl
+        counts = torch.bincount(key, minlength=n_tb * R)
+        # inside every (tile, block): rows ordered by their entry count, descending (stable)
+        order = torch.argsort(counts.view(n_tb, R), dim=1, descending=True, stable=True)       # [n_tb, R] row of position k
+        inv = torch.empty_like(order)
+        inv.scatter_(1, order, torch.arange(R, device=dev).expand(n_tb, R))                    # position of row r
+        sorted_counts = torch.gather(counts.view(n_tb, R), 1, order).reshape(-1)
+        del counts
+        ptr2 = torch.zeros(n_tb * R + 1, dtype=torch.int64, device=dev)
+        ptr2[1:] = torch.cumsum(sorted_counts, 0)
+        del sorted_counts
+        max_run = int((ptr2[R::R] - ptr2[:-1:R]).max())     # longest (tile, block) segment (informational)
+        ar = torch.arange(nnz, device=dev, dtype=torch.int64)
+        is_start = torch.ones(nnz, dtype=torch.bool, device=dev)
+        is_start[1:] = key[1:] != key[:-1]
+        start_idx = torch.cummax(torch.where(is_start, ar, torch.zeros_like(ar)), 0)[0]
+        pos_key = torch.div(key, R, rounding_mode="floor") * R + inv.reshape(-1)[key]          # (tb, sorted position)
+        dest = ptr2[pos_key] + (ar - start_idx)
+        del ar, is_start, start_idx, key, pos_key, inv
+        ent = torch.empty((nnz, 2), dtype=torch.int32, device=dev)
+        ent[dest, 0] = idx - blk * CB
+        ent[dest, 1] = val.view(torch.int32)
+        del dest, blk
+        perm = order.reshape(-1).to(torch.int32).contiguous()
+        del order
+        owner = torch.repeat_interleave(torch.arange(n_tiles, device=dev), nbt)
+        blk_id = (lo[owner].long() + (torch.arange(n_tb, device=dev) - tile_blk[owner])).to(torch.int32)
+        keep = dict(tile_blk=tile_blk.to(torch.int32).contiguous(), blk_id=blk_id.contiguous(),
+                    ptr2=ptr2.to(torch.int32).contiguous(), perm=perm, ent=ent.contiguous())
+        torch.cuda.synchronize()
+        _lib.check(L.mllp_graph_attach_tiled(self._h, int(transpose), n_tiles, n_tb, max_nbt, _lib.ptr(keep["tile_blk"]),
+                                             _lib.ptr(keep["blk_id"]), _lib.ptr(keep["ptr2"]), _lib.ptr(keep["perm"]),
+                                             _lib.ptr(keep["ent"])))
+        if not hasattr(self, "_tiled"):
+            self._tiled = {}
+        self._tiled[bool(transpose)] = keep          # the library borrows these arrays
+        return dict(rows_per_tile=R, cols_per_block=CB, n_tiles=n_tiles, n_tb=n_tb, max_run=max_run,
+                    staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
+
+    def disable_tiled(self, transpose=False):
+        _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), 0, 0, 0, c_void_p(0), c_void_p(0),
+                                                      c_void_p(0), c_void_p(0), c_void_p(0)))
+        if hasattr(self, "_tiled"):
+            self._tiled.pop(bool(transpose), None)
+
     def __del__(self):
         try:
             if self._h is not None and self._h.value:

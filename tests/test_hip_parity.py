@@ -353,3 +353,33 @@ def test_experiment_driver_end_to_end(tmp_path, monkeypatch, golden):
     np.testing.assert_allclose(got[keep], o1.flatten_state(tr.sd).detach().numpy()[keep], rtol=2e-4, atol=3e-6)
     assert any(l.startswith("epoch 1, obj=") for l in lines) and any("Model saved to" in l for l in lines)
     assert sum(1 for l in lines if l.count(",") == 3) == 6          # one metrics line per instance and epoch
+
+
+def test_tiled_spmm_equals_generic_and_oracle(LPBatch):
+    """LDS-tiled SpMM (row tiles x column blocks, tiles and blocks straddling instances) vs the generic sweep
+    and vs scipy, both orientations; unqualified matrices are refused."""
+    from mllp_amd.graph import synthetic_batch
+    sb = synthetic_batch(n_inst=5, m=700, n=1300, mean_row_nnz=24.0, seed=31, chunk=2)
+    rng = np.random.default_rng(2)
+    for transpose in (False, True):
+        n_in, n_out = (sb.M, sb.N) if transpose else (sb.N, sb.M)
+        H = torch.tensor(rng.standard_normal((n_in, 16)).astype(np.float32), device="cuda")
+        ref = sb.spmm(H, transpose=transpose).cpu().numpy()
+        info = sb.enable_tiled(transpose)
+        assert info is not None and info["n_tiles"] == (n_out + info["rows_per_tile"] - 1) // info["rows_per_tile"]
+        got = sb.spmm(H, transpose=transpose).cpu().numpy()
+        close(got, ref, 2e-6, f"tiled vs generic (transpose={transpose})")
+        base = 3 if transpose else 0
+        ptr, idx, val = sb.export(base), sb.export(base + 1), sb.export(base + 2)
+        close(got, o2.spmm(ptr, idx, val.astype(np.float64), H.cpu().numpy().astype(np.float64)), 2e-6, "tiled vs scipy")
+        sb.disable_tiled(transpose)
+        again = sb.spmm(H, transpose=transpose).cpu().numpy()
+        np.testing.assert_array_equal(again, ref)
+    # a (tile, block) segment longer than the LDS window (6144 entries) is processed in several windows
+    dense_rows = synthetic_batch(n_inst=1, m=1024, n=1000, mean_row_nnz=40.0, seed=3, chunk=1)
+    info = dense_rows.enable_tiled(False)
+    assert info is not None and info["max_run"] > 2 * 6144
+    H = torch.randn(dense_rows.N, 16, device="cuda")
+    got = dense_rows.spmm(H).cpu().numpy()
+    dense_rows.disable_tiled(False)
+    close(got, dense_rows.spmm(H).cpu().numpy(), 2e-6, "multi-window segment")

@@ -70,14 +70,14 @@ static int build_tiers(mllp_graph* g, Orient& o, const int* h_ptr) {
         else rg.push_back(r);
     }
     o.n_group = (int)rg.size();
+    o.tier_wave = g->tier_wave;
+    o.short_rows = o.n_dst > 0 && (double)h_ptr[o.n_dst] / o.n_dst <= 16.0;
     o.n_wave = (int)rw.size();
     o.n_chunk = (int)(ck.size() / 4);
     o.n_split = (int)(sp.size() / 4);
     o.n_slots = slots;
     int rc;
-    if (o.n_wave == 0 && o.n_chunk == 0) {
-        o.rows_group = nullptr;  // identity
-    } else if ((rc = upload(g, rg.data(), rg.size(), &o.rows_group))) return rc;
+    o.rows_group = nullptr;  // the group tier visits every row and skips the long ones in-kernel
     if ((rc = upload(g, rw.data(), rw.size(), &o.rows_wave))) return rc;
     if ((rc = upload(g, ck.data(), ck.size(), &o.chunks))) return rc;
     if ((rc = upload(g, sp.data(), sp.size(), &o.split))) return rc;

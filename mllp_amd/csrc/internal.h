@@ -52,6 +52,8 @@ struct Orient {
     int* chunks = nullptr;      // [n_chunk] int4 {row, beg, end, slot}; slot < 0: the row's only chunk
     int* split = nullptr;       // [n_split] int4 {row, first_slot, n_chunks, 0}: rows cut into several chunks
     int n_group = 0, n_wave = 0, n_chunk = 0, n_split = 0, n_slots = 0;
+    int tier_wave = 0;          // rows with more nonzeros than this are skipped by the group tier
+    bool short_rows = false;    // mean row length <= 16: group tier runs one nonzero slot per pass
 };
 constexpr int SCRATCH_NS = 20;  // floats per partial-state slot of a split row
 

@@ -33,21 +33,21 @@ struct OrientDev {
     const int* __restrict__ ptr;
     const int* __restrict__ idx;
     const float* __restrict__ val;
-    const int* __restrict__ rows_group;
     const int* __restrict__ rows_wave;
     const int4* __restrict__ chunks;   // {row, beg, end, slot}; slot < 0: the row's only chunk
     const int4* __restrict__ split;    // {row, first_slot, n_chunks, 0}
-    int n_group, n_wave, n_chunk, n_split, nbA, nbB;
+    int n_dst, n_wave, n_chunk, n_split, nbA, nbB, tier_wave;
 };
 
 static OrientDev make_dev(const Orient& o) {
     OrientDev d;
     d.ptr = o.ptr; d.idx = o.idx; d.val = o.val;
-    d.rows_group = o.rows_group; d.rows_wave = o.rows_wave;
+    d.rows_wave = o.rows_wave;
     d.chunks = reinterpret_cast<const int4*>(o.chunks);
     d.split = reinterpret_cast<const int4*>(o.split);
-    d.n_group = o.n_group; d.n_wave = o.n_wave; d.n_chunk = o.n_chunk; d.n_split = o.n_split;
-    d.nbA = (o.n_group + 15) / 16;
+    d.n_dst = o.n_dst; d.n_wave = o.n_wave; d.n_chunk = o.n_chunk; d.n_split = o.n_split;
+    d.tier_wave = o.tier_wave;
+    d.nbA = (o.n_dst + 15) / 16;   // the group tier visits every row and skips the long ones: no index list to chase
     d.nbB = (o.n_wave + 3) / 4;
     return d;
 }
@@ -69,10 +69,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, Or
     const int b = blockIdx.x;
     if (b < o.nbA) {
         const int tile = xcd_tile(b, o.nbA);
-        const int slot = tile * 16 + wave * 4 + (lane >> 4);
-        if (slot < o.n_group) {
-            const int row = o.rows_group ? o.rows_group[slot] : slot;
-            const int beg = o.ptr[row], end = o.ptr[row + 1];
+        const int row = tile * 16 + wave * 4 + (lane >> 4);
+        int beg = 0, end = 0;
+        if (row < o.n_dst) {
+            beg = o.ptr[row];
+            end = o.ptr[row + 1];
+        }
+        if (row < o.n_dst && end - beg <= o.tier_wave) {   // longer rows belong to the wave / chunk tiers
             Op op;
             op.load_row(args, row, end - beg, lane & 15);
             op.template edges<16, UA>(args, o, beg, end, 0, (16 / Op::LPN) * UA, lane & 15);
@@ -266,13 +269,21 @@ struct Fwd16Op {
     using Args = FwdArgs;
     static constexpr int NS = 20, LPN = 4;   // {m, L, u, -, Z[16]}
     float4 qp, Z;
-    float t, m, L, u;
+    float t, m, L, u, skip;
     int part;
 
     __device__ __forceinline__ void load_row(const Args& args, int row, int, int gl) {
         part = gl & 3;
         qp = ld4(args.qp + (size_t)row * 16 + 4 * part);
         t = args.t[row];
+        {   // root/skip term Ws x_i + bs of output channel (gl & 15): independent of the sweep, so its loads
+            // are issued with the row's first round trip instead of after the reduction
+            const int c = gl & 15;
+            float xr[16], ws[16];
+            load_row16(args.xd + (size_t)row * 16, xr);
+            load_row16(args.p.Ws + c * 16, ws);
+            skip = dot16(ws, xr, args.p.bs[c]);
+        }
         m = NEG_BIG;
         L = 0.0f;
         u = 0.0f;
@@ -347,16 +358,13 @@ struct Fwd16Op {
         const float S = L * rinv;
         const float un = u * rinv;
         const float4 zn = make_float4(Z.x * rinv, Z.y * rinv, Z.z * rinv, Z.w * rinv);
-        float za[16], xr[16], wv[16], ws[16];
+        float za[16], wv[16];
         quad_allgather(zn, za);
-        load_row16(args.xd + (size_t)row * 16, xr);
         load_row16(args.p.Wv + gl * 16, wv);
-        load_row16(args.p.Ws + gl * 16, ws);
-        float o = args.p.bs[gl];
+        float o = skip;
         o = fmaf(S, args.p.bv[gl], o);
         o = fmaf(un, args.p.we[gl], o);
         o = dot16(wv, za, o);
-        o = dot16(ws, xr, o);
         args.h[(size_t)row * 16 + gl] = fmaxf(o, 0.0f);
         if (gl < 4) *reinterpret_cast<float4*>(args.Z + (size_t)row * 16 + 4 * gl) = zn;
         if (gl == 0) reinterpret_cast<float4*>(args.aux)[row] = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);
@@ -475,11 +483,18 @@ struct BwdDst16Op {
     using Args = BwdDstArgs;
     static constexpr int NS = 20, LPN = 4;   // {ds, dt, -, -, dqp[16]}
     float4 qp, gv, dqp;
-    float t, m, rinv, ge, cc, ds, dt;
+    float t, m, rinv, ge, cc, ds, dt, v0;
     int part;
 
     __device__ __forceinline__ void load_row(const Args& args, int row, int, int gl) {
         part = gl & 3;
+        v0 = 0.0f;
+        if (args.dx_dst) {   // Ws^T g_i of input channel (gl & 15): independent of the sweep, loaded up front
+            float gr[16], wsT[16];
+            load_row16(args.g + (size_t)row * 16, gr);
+            load_row16(args.derived + OFF_WST + (gl & 15) * 16, wsT);
+            v0 = dot16(wsT, gr, 0.0f);
+        }
         const float* r = args.rec + (size_t)row * REC_W;
         qp = ld4(r + 4 * part);
         gv = ld4(r + 16 + 4 * part);
@@ -542,14 +557,11 @@ struct BwdDst16Op {
         if (gl == 0) reinterpret_cast<float2*>(args.dsdt)[row] = make_float2(ds, dt);
         if (args.dx_dst) {
             const float* D = args.derived;
-            float da[16], gr[16], wsT[16], pqT[16];
+            float da[16], pqT[16];
             quad_allgather(dqp, da);
-            load_row16(args.g + (size_t)row * 16, gr);
-            load_row16(D + OFF_WST + gl * 16, wsT);   // WsT[gl][o] = Ws[o][gl]
             load_row16(D + OFF_PQT + gl * 16, pqT);   // PqT[gl][k] = Pq[k][gl]
-            float v = ds * D[OFF_PB + gl];
+            float v = fmaf(ds, D[OFF_PB + gl], v0);
             v = fmaf(dt, D[OFF_PT + gl], v);
-            v = dot16(wsT, gr, v);
             v = dot16(pqT, da, v);
             float* dst = args.dx_dst + (size_t)row * 16 + gl;
             *dst = args.accumulate ? *dst + v : v;
@@ -701,6 +713,9 @@ struct BwdSrc16Op {
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
+// UA: nonzero slots per lane group and pass in the group tier.  Short rows dominate the latency regime (real
+// Netlib: median 2-4 nonzeros per row), where every unrolled slot is executed instruction for instruction even
+// when it is masked off, so UA = 1 there; the throughput regime (rows of 100+) wants the loads of 4 slots in flight.
 template <class Op, int UA, int UB>
 static int launch_sweep(const Orient& o, const typename Op::Args& args, float* scratch, hipStream_t s,
                         const char* name) {
@@ -709,7 +724,10 @@ static int launch_sweep(const Orient& o, const typename Op::Args& args, float* s
     const int64_t blocks = (int64_t)d.nbA + d.nbB + d.n_chunk;
     if (blocks == 0) return MLLP_OK;
     if (blocks >= INT32_MAX) return fail(MLLP_ERANGE, "too many workgroups");
-    hipLaunchKernelGGL((sweep_kernel<Op, UA, UB>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args, d, scratch);
+    if (o.short_rows)
+        hipLaunchKernelGGL((sweep_kernel<Op, 1, UB>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args, d, scratch);
+    else
+        hipLaunchKernelGGL((sweep_kernel<Op, UA, UB>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args, d, scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, name);
     if (d.n_split > 0) {

@@ -276,14 +276,7 @@ struct Fwd16Op {
         part = gl & 3;
         qp = ld4(args.qp + (size_t)row * 16 + 4 * part);
         t = args.t[row];
-        {   // root/skip term Ws x_i + bs of output channel (gl & 15): independent of the sweep, so its loads
-            // are issued with the row's first round trip instead of after the reduction
-            const int c = gl & 15;
-            float xr[16], ws[16];
-            load_row16(args.xd + (size_t)row * 16, xr);
-            load_row16(args.p.Ws + c * 16, ws);
-            skip = dot16(ws, xr, args.p.bs[c]);
-        }
+        skip = 0.0f;   // (hoisting the root term Ws x_i + bs here cost 26 VGPRs and 14 % on the large batches)
         m = NEG_BIG;
         L = 0.0f;
         u = 0.0f;
@@ -358,13 +351,16 @@ struct Fwd16Op {
         const float S = L * rinv;
         const float un = u * rinv;
         const float4 zn = make_float4(Z.x * rinv, Z.y * rinv, Z.z * rinv, Z.w * rinv);
-        float za[16], wv[16];
+        float za[16], xr[16], wv[16], ws[16];
         quad_allgather(zn, za);
+        load_row16(args.xd + (size_t)row * 16, xr);
         load_row16(args.p.Wv + gl * 16, wv);
-        float o = skip;
+        load_row16(args.p.Ws + gl * 16, ws);
+        float o = args.p.bs[gl] + skip;
         o = fmaf(S, args.p.bv[gl], o);
         o = fmaf(un, args.p.we[gl], o);
         o = dot16(wv, za, o);
+        o = dot16(ws, xr, o);
         args.h[(size_t)row * 16 + gl] = fmaxf(o, 0.0f);
         if (gl < 4) *reinterpret_cast<float4*>(args.Z + (size_t)row * 16 + 4 * gl) = zn;
         if (gl == 0) reinterpret_cast<float4*>(args.aux)[row] = make_float4(un, deg > 0 ? m : 0.0f, rinv, S);

@@ -10,6 +10,7 @@ instances of the per-instance mean BCE divided by the GLOBAL instance count, hen
 gradients equal the single-GPU batch gradient.  One all-reduce of the flat 4721-float gradient buffer
 (18.9 KB, latency bound) per step; weights stay replicated because every rank applies the same Adam.
 """
+import os
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -72,7 +73,8 @@ class FlatAdam:
 
 def allreduce_sum_(t: torch.Tensor):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("MLLP_BENCH_FORCE_DIST") == "1"):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -141,7 +143,8 @@ class LPTrainer:
         """One optimizer step on `batch`; returns (loss, logits) device tensors (valid until the next step)."""
         import torch.distributed as dist
         p = self._plan(batch)
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        multi = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("MLLP_BENCH_FORCE_DIST") == "1")
         if not self.use_graph or p["warm"] < 1:
             self._fwd_bwd(p)
             if multi:

@@ -36,20 +36,33 @@ static int conv_forward(const mllp_graph* g, bool dst_is_var, int cin, const flo
     int rc;
     if ((rc = launch_param_prep(cp, cin, w.derived, s))) return rc;
     if (cin == 16 && (rc = launch_node_qp(x_dst, o.n_dst, w.derived, w.qp, w.t, s))) return rc;
-    return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, g->scratch, s);
+    return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, o.scratch, s);
 }
 
 // dh is overwritten with the ReLU-masked gradient; dx_* may be null; acc bit0 -> dx_dst, bit1 -> dx_src
+// fork: work queued on `to` after this point waits for everything queued on `from` so far (capturable)
+static int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    MLLP_HIP_TRY(hipEventRecord(ev, from));
+    MLLP_HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+    return MLLP_OK;
+}
+
+// fin: stream of the single-workgroup finalize kernel (s itself, or the graph's aux stream with event ev)
 static int conv_backward(const mllp_graph* g, bool dst_is_var, int cin, const float* cp, const ConvWs& w,
                          const float* x_src, const float* x_dst, const float* h_out, float* dh, float* dx_dst,
-                         float* dx_src, int acc, float* param_grads, hipStream_t s) {
+                         float* dx_src, int acc, float* param_grads, hipStream_t s, hipStream_t fin = nullptr,
+                         hipEvent_t ev = nullptr) {
     const Orient& o = dst_is_var ? g->At : g->A;       // destination-major
     const Orient& ot = dst_is_var ? g->A : g->At;      // source-major (rows = source nodes)
     int rc;
     if ((rc = launch_bwd_pre(o.n_dst, cin, cp, w, x_dst, h_out, dh, s))) return rc;
-    if ((rc = launch_attn_bwd_dst(o, cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, g->scratch, s))) return rc;
-    if (cin == 16 && dx_src && (rc = launch_attn_bwd_src(ot, w, x_src, dx_src, (acc >> 1) & 1, g->scratch, s))) return rc;
+    if ((rc = launch_attn_bwd_dst(o, cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, o.scratch, s))) return rc;
+    if (cin == 16 && dx_src && (rc = launch_attn_bwd_src(ot, w, x_src, dx_src, (acc >> 1) & 1, ot.scratch, s))) return rc;
     if ((rc = launch_param_stats(cin, o.n_dst, w, x_dst, dh, s))) return rc;
+    if (fin && fin != s) {
+        if ((rc = fork_to(s, fin, ev))) return rc;
+        return launch_finalize_conv(cin, cp, w.stats, stat_blocks_for(o.n_dst), param_grads, fin);
+    }
     return launch_finalize_conv(cin, cp, w.stats, stat_blocks_for(o.n_dst), param_grads, s);
 }
 
@@ -98,12 +111,18 @@ constexpr int OFF_C1V = 0, OFF_C1C = 144, OFF_C2V = 288, OFF_C2C = 1392, OFF_C3V
 static int model_forward_body(const mllp_graph* g, const float* P, const float* x1, const float* x2, const ModelWs& w,
                               hipStream_t s) {
     int rc;
-    // linear_program_methods.py:241-242  layer 1 (scalar inputs), both directions from the SAME inputs
+    hipStream_t a = g->aux;
+    // linear_program_methods.py:241-242  layer 1 (scalar inputs), both directions from the SAME inputs:
+    // the w2s conv walks A^T, the s2w conv walks A -- independent, so they run on two streams
+    if ((rc = fork_to(s, a, g->ev[0]))) return rc;
     if ((rc = conv_forward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, s))) return rc;
-    if ((rc = conv_forward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, s))) return rc;
+    if ((rc = conv_forward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, a))) return rc;
+    if ((rc = fork_to(a, s, g->ev[1]))) return rc;       // join: layer 2 on s needs h1c
+    if ((rc = fork_to(s, a, g->ev[2]))) return rc;       // ... and layer 2 on aux needs h1v
     // :244-245  layer 2 (simultaneous update: both read layer-1 outputs)
     if ((rc = conv_forward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, s))) return rc;
-    if ((rc = conv_forward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, s))) return rc;
+    if ((rc = conv_forward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, a))) return rc;
+    if ((rc = fork_to(a, s, g->ev[3]))) return rc;       // join
     // :247  layer 3, variables only (gconv3_s2w is never called, :248)
     return conv_forward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, s);
 }
@@ -111,17 +130,22 @@ static int model_forward_body(const mllp_graph* g, const float* P, const float* 
 static int model_backward_body(const mllp_graph* g, const float* P, const float* x1, const float* x2,
                                const ModelWs& w, float* grads, hipStream_t s) {
     int rc;
+    hipStream_t a = g->aux;     // already forked from s by the caller (head_finalize runs there)
+    // the single-workgroup finalize kernels go to the aux stream, off the critical path
     if ((rc = conv_backward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, w.d3v, w.d2v, w.d2c, 0,
-                            grads + OFF_C3V, s))) return rc;
+                            grads + OFF_C3V, s, a, g->ev[4]))) return rc;
     if ((rc = conv_backward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, w.d2v, w.d1v, w.d1c, 0,
-                            grads + OFF_C2V, s))) return rc;
+                            grads + OFF_C2V, s, a, g->ev[5]))) return rc;
     if ((rc = conv_backward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, w.d2c, w.d1c, w.d1v, 3,
-                            grads + OFF_C2C, s))) return rc;
+                            grads + OFF_C2C, s, a, g->ev[6]))) return rc;
+    // layer 1: the two convs are independent (their inputs are data): one per stream
+    if ((rc = fork_to(s, a, g->ev[7]))) return rc;       // aux needs d1c (complete on s)
     if ((rc = conv_backward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, w.d1v, nullptr, nullptr, 0,
                             grads + OFF_C1V, s))) return rc;
     if ((rc = conv_backward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, w.d1c, nullptr, nullptr, 0,
-                            grads + OFF_C1C, s))) return rc;
-    return launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, s);
+                            grads + OFF_C1C, a))) return rc;
+    if ((rc = launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, a))) return rc;
+    return fork_to(a, s, g->ev[0]);                      // join everything queued on aux
 }
 
 }  // namespace mllp
@@ -133,7 +157,8 @@ using namespace mllp;
 
 extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream) {
     REQUIRE(g && d_H && d_Y, "null argument");
-    return launch_spmm(transpose ? g->At : g->A, d_H, d_Y, g->scratch, (hipStream_t)stream);
+    const Orient& o = transpose ? g->At : g->A;
+    return launch_spmm(o, d_H, d_Y, o.scratch, (hipStream_t)stream);
 }
 
 extern "C" int mllp_tiled_geometry(int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity) {
@@ -218,7 +243,8 @@ extern "C" int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, c
     int rc;
     if ((rc = launch_head(1, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f,
                           d_dlogits, nullptr, w.d3v, w.head_partials, s))) return rc;
-    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, s))) return rc;
+    if ((rc = fork_to(s, g->aux, g->ev[1]))) return rc;
+    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, g->aux))) return rc;
     return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
 }
 
@@ -232,7 +258,8 @@ extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, 
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
     if ((rc = launch_head(2, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, d_labels, inv_batch,
                           nullptr, d_logits, w.d3v, w.head_partials, s))) return rc;
-    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, d_loss, s))) return rc;
+    if ((rc = fork_to(s, g->aux, g->ev[1]))) return rc;
+    if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, d_loss, g->aux))) return rc;
     return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
 }
 

@@ -99,13 +99,14 @@ static int finish_common(mllp_graph* g) {
         ipm[k] = (int)g->h_inst_ptr_m[k];
     }
     int rc;
-    {
-        const size_t slots = (size_t)std::max(std::max(g->A.n_slots, g->At.n_slots), 1);
+    for (Orient* o : {&g->A, &g->At}) {
         void* p = nullptr;
-        MLLP_HIP_TRY(hipMalloc(&p, slots * SCRATCH_NS * sizeof(float)));
+        MLLP_HIP_TRY(hipMalloc(&p, (size_t)std::max(o->n_slots, 1) * SCRATCH_NS * sizeof(float)));
         g->allocs.push_back(p);
-        g->scratch = static_cast<float*>(p);
+        o->scratch = static_cast<float*>(p);
     }
+    MLLP_HIP_TRY(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
+    for (auto& e : g->ev) MLLP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if ((rc = upload(g, inv_n.data(), inv_n.size(), &g->inv_n))) return rc;
     if ((rc = upload(g, ipn.data(), ipn.size(), &g->inst_ptr_n))) return rc;
     if ((rc = upload(g, ipm.data(), ipm.size(), &g->inst_ptr_m))) return rc;
@@ -289,6 +290,9 @@ extern "C" int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_
 extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     if (!g) return MLLP_OK;
     for (void* p : g->allocs) (void)hipFree(p);
+    for (auto& e : g->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (g->aux) (void)hipStreamDestroy(g->aux);
     delete g;
     return MLLP_OK;
 }

@@ -52,6 +52,7 @@ struct Orient {
     int* chunks = nullptr;      // [n_chunk] int4 {row, beg, end, slot}; slot < 0: the row's only chunk
     int* split = nullptr;       // [n_split] int4 {row, first_slot, n_chunks, 0}: rows cut into several chunks
     int n_group = 0, n_wave = 0, n_chunk = 0, n_split = 0, n_slots = 0;
+    float* scratch = nullptr;   // [n_slots x SCRATCH_NS] partial states of this orientation's split rows
     int tier_wave = 0;          // rows with more nonzeros than this are skipped by the group tier
     bool short_rows = false;    // mean row length <= 16: group tier runs one nonzero slot per pass
 };
@@ -69,7 +70,10 @@ struct mllp_graph {
     std::vector<int64_t> h_inst_ptr_n, h_inst_ptr_m;
     int tier_wave = 0, tier_block = 0, chunk_nnz = 0;
     int max_inst_n = 0;
-    float* scratch = nullptr;    // partial states of split rows (sweeps on one graph must be stream-ordered)
+    // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
+    // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev[8] = {};
     std::vector<void*> allocs;   // everything to hipFree on destroy
 };
 

@@ -248,8 +248,10 @@ def test_adam_and_trainer_follow_reference_loop(LPBatch, subset5, golden, weight
         losses = [float(tr.step(afiro)[0][0]) for _ in range(3)]
         np.testing.assert_allclose(losses, golden["afiro_adam3_losses"], rtol=2e-5)
         keep = grad_mask()
+        # Adam divides by sqrt(v): parameters whose gradient is at rounding-noise level move by a noisy O(lr);
+        # 1e-5 absolute is 0.3 % of the 3e-3 a parameter can travel in three steps at lr = 1e-3
         np.testing.assert_allclose(tr.params.cpu().numpy()[keep], golden["afiro_adam3_weights"][keep],
-                                   rtol=1e-4, atol=2e-6)
+                                   rtol=1e-4, atol=1e-5)
         assert float(tr.opt.state[0]) == 3.0
     # gconv3_s2w is never called (reference methods.py:248): it receives zero gradient and never moves
     np.testing.assert_array_equal(tr.params.cpu().numpy()[3600:4704], flat.astype(np.float32)[3600:4704])

@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-synthetic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hip-graph", action="store_true")
+    ap.add_argument("--hip-graph", default="auto", help="auto (capture only launch-bound batches) | True")
     return ap.parse_args()
 
 
@@ -141,7 +142,8 @@ def main():
 
     # ---------------- headline: Netlib batch, instances/s --------------------------------------
     batch = LPBatch.from_instances(instances)
-    trainer = LPTrainer(params0, lr=1e-3, use_hip_graph=not args.no_hip_graph, global_instances=n_inst * world)
+    trainer = LPTrainer(params0, lr=1e-3, use_hip_graph=False if args.no_hip_graph else args.hip_graph,
+                        global_instances=n_inst * world)
     for _ in range(max(args.warmup, 2)):          # >= 2: eager pass + graph capture
         trainer.step(batch)
     barrier_sync(dist_on)
@@ -160,7 +162,8 @@ def main():
                                 "synthetic sparse LPs for the roofline section",
         "config": {"workload": "netlib_full: BASELINE.json configs[2], 97 instances / 1,074,147 nnz as one "
                                "block-diagonal batch per GPU and step, fwd + BCE + bwd + Adam, fp32",
-                   "instances_per_gpu": n_inst, "nnz_per_gpu": batch.nnz, "hip_graph": not args.no_hip_graph,
+                   "instances_per_gpu": n_inst, "nnz_per_gpu": batch.nnz,
+                   "hip_graph": bool(trainer._plans[id(batch)]["graph"]),
                    "parallelism": f"dp{world}", "final_loss_rank0": loss_end},
     }
     del trainer

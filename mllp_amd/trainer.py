@@ -100,8 +100,10 @@ class LPTrainer:
     """HIP fast path: one `mllp_gnn_loss_step` + all-reduce + `mllp_adam_step` per batch, optionally
     captured in hipGraphs (the Netlib batch is launch bound: ~30 small kernels per step)."""
 
-    def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph=True, global_instances: Optional[int] = None,
-                 with_metrics=False):
+    GRAPH_NNZ_LIMIT = 1 << 18   # "auto": capture batches up to this many nonzeros (launch-bound), run larger ones eagerly
+
+    def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph="auto",
+                 global_instances: Optional[int] = None, with_metrics=False):
         assert params_flat.is_cuda and params_flat.numel() == NUM_PARAMS
         self.params = params_flat.detach().clone().float().contiguous()
         self.opt = FlatAdam(self.params, lr=lr)
@@ -115,9 +117,13 @@ class LPTrainer:
         p = self._plans.get(key)
         if p is None:
             dev = self.params.device
+            # hipGraph replay removes ~40 host launches per step, which is what bounds tiny batches (one small
+            # instance per step); on the full Netlib batch the step is ~1 ms of GPU work and eager launches on two
+            # streams measured faster (0.99 ms) than replaying the captured graph (1.08 ms)
+            graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),
-                     g_fwd=None, g_opt=None, warm=0)
+                     g_fwd=None, g_opt=None, warm=0, graph=graph)
             self._plans[key] = p
         return p
 
@@ -145,7 +151,7 @@ class LPTrainer:
         p = self._plan(batch)
         multi = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size() > 1 or os.environ.get("MLLP_BENCH_FORCE_DIST") == "1")
-        if not self.use_graph or p["warm"] < 1:
+        if not p["graph"] or p["warm"] < 1:
             self._fwd_bwd(p)
             if multi:
                 allreduce_sum_(p["grads"])

@@ -381,3 +381,44 @@ def test_tiled_spmm_equals_generic_and_oracle(LPBatch):
     got = dense_rows.spmm(H).cpu().numpy()
     dense_rows.disable_tiled(False)
     close(got, dense_rows.spmm(H).cpu().numpy(), 2e-6, "multi-window segment")
+
+
+def test_dropin_batched_graph_equals_per_graph(subset5, weights):
+    """GNNModel on BipartiteData.batch([...]) (the __inc__ rule, reference methods.py:68-70) == per-graph calls;
+    edge order of the input does not matter (the graph is re-sorted into CSR order when it is built)."""
+    from mllp_amd.model import BipartiteData, GNNModel, build_graph_from_weights_sets
+    flat, sd, flat_gpu = weights
+    model = GNNModel().to("cuda")
+    model.load_flat(flat_gpu)
+    graphs = []
+    for inst in subset5[:3]:
+        name, constrs, w, coefs, rhs, basis = inst.as_reference_tuple()
+        graphs.append(build_graph_from_weights_sets(constrs, w, rhs, coefs, torch.device("cuda")))
+    with torch.no_grad():
+        singles = torch.cat([model(g) for g in graphs])
+        batched = model(BipartiteData.batch(graphs))
+        g0 = graphs[0]
+        perm = torch.randperm(g0.edge_index.shape[1], generator=torch.Generator().manual_seed(3)).to("cuda")
+        shuffled = model(BipartiteData(g0.edge_index[:, perm], g0.x1, g0.x2, g0.edge_attr[perm]))
+    np.testing.assert_allclose(batched.cpu().numpy(), singles.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(shuffled.cpu().numpy(), singles[:subset5[0].n].cpu().numpy(), rtol=0, atol=0)
+    ref = o1.gnn_forward(o1.unflatten_state(torch.tensor(flat)), *o1.batch_graphs(
+        [o1.instance_graph(i, torch.float64) for i in subset5[:3]])).numpy()
+    close(batched.cpu().numpy(), ref, RTOL_ACT, "batched drop-in logits")
+
+
+def test_c_abi_argument_errors(LPBatch, subset5):
+    """error behaviour of the boundary: negative code + message, nothing launched"""
+    from mllp_amd import _lib
+    L = _lib.lib()
+    b = LPBatch.from_instances(subset5[:1])
+    H = torch.zeros(b.N, 16, device="cuda")
+    assert L.mllp_spmm_csr_f32(b._h, 0, _lib.ptr(H), None, None) == -1 and b"null" in L.mllp_last_error()
+    n = __import__("ctypes").c_int64()
+    assert L.mllp_tconv_workspace_floats(b._h, 0, 7, __import__("ctypes").byref(n)) == -1
+    assert b"cin must be 1 or 16" in L.mllp_last_error()
+    with pytest.raises(AssertionError):
+        b.spmm(torch.zeros(b.N + 1, 16, device="cuda"))
+    with pytest.raises(_lib.MllpError):
+        _lib.check(L.mllp_graph_attach_tiled(b._h, 0, 3, 5, 1, _lib.ptr(H), _lib.ptr(H), _lib.ptr(H), _lib.ptr(H),
+                                             _lib.ptr(H)))            # wrong tile count for this graph

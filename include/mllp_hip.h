@@ -109,9 +109,11 @@ int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, fl
  *   d_perm     [n_tb * rows_per_tile]      row (inside its tile) of every sorted position
  *   d_ent      [nnz][2]     {column id inside its block, fp32 value bits}, ordered by (tile, block, position, column)
  * The arrays are BORROWED: the caller keeps them alive while attached (n_tiles = 0 detaches).
- * With a tiled copy attached mllp_spmm_csr_f32 uses it for that orientation.                       */
-int mllp_tiled_geometry(int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity);
-int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int64_t n_tiles, int64_t n_tb,
+ * variant 0 is the geometry of the plain SpMM (mllp_spmm_csr_f32 uses it when attached), variant 1 the
+ * geometry of the attention sweeps (the forward sweep of mllp_tconv_fwd / mllp_gnn_* uses it when attached:
+ * it keeps the per-row query and softmax state in LDS, hence smaller column blocks).                */
+int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity);
+int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int variant, int64_t n_tiles, int64_t n_tb,
                             int32_t max_blocks_per_tile /* largest tile_blk[t+1]-tile_blk[t]; at most 255 */,
                             const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
                             const int32_t* d_perm, const int32_t* d_ent);

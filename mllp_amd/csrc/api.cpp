@@ -161,34 +161,38 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
     return launch_spmm(o, d_H, d_Y, o.scratch, (hipStream_t)stream);
 }
 
-extern "C" int mllp_tiled_geometry(int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity) {
+extern "C" int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block,
+                                   int32_t* bundle_capacity) {
     REQUIRE(rows_per_tile && cols_per_block && bundle_capacity, "null argument");
+    REQUIRE(variant == 0 || variant == 1, "variant must be 0 (SpMM) or 1 (attention sweeps)");
     int a, b, c;
-    tiled_geometry(&a, &b, &c);
+    tiled_geometry(variant, &a, &b, &c);
     *rows_per_tile = a; *cols_per_block = b; *bundle_capacity = c;
     return MLLP_OK;
 }
 
-extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int64_t n_tiles, int64_t n_tb,
+extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int variant, int64_t n_tiles, int64_t n_tb,
                                        int32_t max_blocks_per_tile,
                                        const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
                                        const int32_t* d_perm, const int32_t* d_ent) {
     REQUIRE(g, "null graph");
+    REQUIRE(variant == 0 || variant == 1, "variant must be 0 (SpMM) or 1 (attention sweeps)");
     Orient& o = transpose ? g->At : g->A;
+    Tiled& tl = variant == 0 ? o.tiled : o.tiled_attn;
     if (n_tiles == 0) {   // detach
-        o.tiled = Tiled();
+        tl = Tiled();
         return MLLP_OK;
     }
     REQUIRE(d_tile_blk && d_blk_id && d_ptr2 && d_perm && d_ent, "null array");
     int R, CB, CAP;
-    tiled_geometry(&R, &CB, &CAP);
+    tiled_geometry(variant, &R, &CB, &CAP);
     REQUIRE(n_tiles == (o.n_dst + R - 1) / R, "n_tiles must be ceil(rows / rows_per_tile)");
     REQUIRE(n_tb > 0 && n_tb * (int64_t)R < INT32_MAX, "bad (tile, block) count");
     REQUIRE(max_blocks_per_tile > 0 && max_blocks_per_tile <= tiled_max_blocks_per_tile(),
             "a row tile touches more column blocks than the kernel's table holds");
-    o.tiled.n_tiles = (int)n_tiles; o.tiled.n_tb = (int)n_tb;
-    o.tiled.tile_blk = d_tile_blk; o.tiled.blk_id = d_blk_id; o.tiled.ptr2 = d_ptr2; o.tiled.perm = d_perm;
-    o.tiled.ent = d_ent;
+    tl.n_tiles = (int)n_tiles; tl.n_tb = (int)n_tb;
+    tl.tile_blk = d_tile_blk; tl.blk_id = d_blk_id; tl.ptr2 = d_ptr2; tl.perm = d_perm;
+    tl.ent = d_ent;
     return MLLP_OK;
 }
 

@@ -42,7 +42,8 @@ struct Tiled {
 };
 
 struct Orient {
-    Tiled tiled;
+    Tiled tiled;        // variant 0: geometry of the plain SpMM
+    Tiled tiled_attn;   // variant 1: geometry of the attention sweeps
     int n_dst = 0, n_src = 0;
     int* ptr = nullptr;    // [n_dst + 1]
     int* idx = nullptr;    // [nnz] source ids
@@ -128,7 +129,10 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
-int tiled_geometry(int* rows_per_tile, int* cols_per_block, int* bundle_capacity);
+struct ConvWs;
+int launch_fwd16_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_params, const ConvWs& w,
+                       const float* x_src, const float* x_dst, float* h_out, hipStream_t s);
+int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bundle_capacity);
 int tiled_max_blocks_per_tile();
 int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s);
 int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s);

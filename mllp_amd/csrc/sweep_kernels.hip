@@ -747,6 +747,8 @@ int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const Co
     a.X = x_src; a.xd = x_dst; a.qp = w.qp; a.t = w.t; a.derived = w.derived;
     a.p = conv_params_at(conv_params, cin);
     a.h = h_out; a.Z = w.Z; a.aux = w.aux;
+    if (cin == 16 && o.tiled_attn.n_tiles > 0)
+        return launch_fwd16_tiled(o.tiled_attn, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     if (cin == 16) return launch_sweep<Fwd16Op, 4, 4>(o, a, scratch, s, "attn_fwd16");
     return launch_sweep<Fwd1Op, 2, 2>(o, a, scratch, s, "attn_fwd1");
 }

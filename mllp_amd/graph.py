@@ -85,13 +85,13 @@ class LPBatch:
         return (torch.from_numpy(self.export(base)).to(dev), torch.from_numpy(self.export(base + 1)).to(dev),
                 torch.from_numpy(self.export(base + 2)).to(dev))
 
-    def enable_tiled(self, transpose=False, arrays=None):
+    def enable_tiled(self, transpose=False, arrays=None, variant=0):
         """Build and attach the LDS-tiled copy of A (transpose=False) or A^T.  Returns a dict with the
         geometry, or None when the matrix does not qualify (index range).
         Re-blocking is done once with torch ops on the device (plumbing, not the hot path)."""
         L = _lib.lib()
         R, CB, CAP = c_int32(), c_int32(), c_int32()
-        _lib.check(L.mllp_tiled_geometry(ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
+        _lib.check(L.mllp_tiled_geometry(int(variant), ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
         R, CB, CAP = R.value, CB.value, CAP.value
         ptr, idx, val = arrays if arrays is not None else self._device_orientation(transpose)
         n_dst = self.N if transpose else self.M
@@ -145,20 +145,21 @@ class LPBatch:
         keep = dict(tile_blk=tile_blk.to(torch.int32).contiguous(), blk_id=blk_id.contiguous(),
                     ptr2=ptr2.to(torch.int32).contiguous(), perm=perm, ent=ent.contiguous())
         torch.cuda.synchronize()
-        _lib.check(L.mllp_graph_attach_tiled(self._h, int(transpose), n_tiles, n_tb, max_nbt, _lib.ptr(keep["tile_blk"]),
+        _lib.check(L.mllp_graph_attach_tiled(self._h, int(transpose), int(variant), n_tiles, n_tb, max_nbt,
+                                             _lib.ptr(keep["tile_blk"]),
                                              _lib.ptr(keep["blk_id"]), _lib.ptr(keep["ptr2"]), _lib.ptr(keep["perm"]),
                                              _lib.ptr(keep["ent"])))
         if not hasattr(self, "_tiled"):
             self._tiled = {}
-        self._tiled[bool(transpose)] = keep          # the library borrows these arrays
+        self._tiled[(bool(transpose), int(variant))] = keep          # the library borrows these arrays
         return dict(rows_per_tile=R, cols_per_block=CB, n_tiles=n_tiles, n_tb=n_tb, max_run=max_run,
                     staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
 
-    def disable_tiled(self, transpose=False):
-        _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), 0, 0, 0, c_void_p(0), c_void_p(0),
-                                                      c_void_p(0), c_void_p(0), c_void_p(0)))
+    def disable_tiled(self, transpose=False, variant=0):
+        _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), int(variant), 0, 0, 0, c_void_p(0),
+                                                      c_void_p(0), c_void_p(0), c_void_p(0), c_void_p(0)))
         if hasattr(self, "_tiled"):
-            self._tiled.pop(bool(transpose), None)
+            self._tiled.pop((bool(transpose), int(variant)), None)
 
     def __del__(self):
         try:

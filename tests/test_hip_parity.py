@@ -420,5 +420,51 @@ def test_c_abi_argument_errors(LPBatch, subset5):
     with pytest.raises(AssertionError):
         b.spmm(torch.zeros(b.N + 1, 16, device="cuda"))
     with pytest.raises(_lib.MllpError):
-        _lib.check(L.mllp_graph_attach_tiled(b._h, 0, 3, 5, 1, _lib.ptr(H), _lib.ptr(H), _lib.ptr(H), _lib.ptr(H),
+        _lib.check(L.mllp_graph_attach_tiled(b._h, 0, 0, 3, 5, 1, _lib.ptr(H), _lib.ptr(H), _lib.ptr(H), _lib.ptr(H),
                                              _lib.ptr(H)))            # wrong tile count for this graph
+
+
+def test_tiled_attention_forward_equals_generic_and_oracle(LPBatch, weights):
+    """LDS-tiled attention forward sweep (variant 1) vs the generic sweep (h, Z, aux bit-for-bit close) and,
+    through the whole model, vs the fp64 oracle; both orientations, tiles straddling instances."""
+    from mllp_amd.graph import synthetic_batch
+    flat, sd, flat_gpu = weights
+    sb = synthetic_batch(n_inst=4, m=600, n=1100, mean_row_nnz=30.0, seed=41, chunk=2)
+    rng = np.random.default_rng(4)
+    for dst_is_var, off in ((False, 1392), (True, 288)):
+        nd, ns = (sb.N, sb.M) if dst_is_var else (sb.M, sb.N)
+        cp = flat_gpu[off:off + 1104].contiguous()
+        xs = torch.tensor(rng.standard_normal((ns, 16)).astype(np.float32), device="cuda")
+        xd = torch.tensor(rng.standard_normal((nd, 16)).astype(np.float32), device="cuda")
+        ws_a, ws_b = sb.tconv_workspace(dst_is_var, 16), sb.tconv_workspace(dst_is_var, 16)
+        h_ref = sb.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws_a)
+        assert sb.enable_tiled(dst_is_var, variant=1) is not None
+        h_til = sb.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws_b)
+        close(h_til.cpu().numpy(), h_ref.cpu().numpy(), 2e-6, "h tiled vs generic")
+        up16 = lambda v: (v + 15) // 16 * 16
+        o_ = up16(1088) + up16(nd * 16) + up16(nd)            # skip derived, q', t  (api.cpp::conv_ws_carve)
+        Za, Zb = ws_a[o_:o_ + nd * 16].cpu().numpy(), ws_b[o_:o_ + nd * 16].cpu().numpy()
+        close(Zb, Za, 2e-6, "Z tiled vs generic")
+        o_ += up16(nd * 16)
+        close(ws_b[o_:o_ + nd * 4].cpu().numpy(), ws_a[o_:o_ + nd * 4].cpu().numpy(), 2e-6, "aux tiled vs generic")
+        # backward consumes what the tiled forward saved
+        dh = torch.tensor(rng.standard_normal((nd, 16)).astype(np.float32), device="cuda")
+        pg_b = sb.tconv_bwd(dst_is_var, 16, cp, xs, xd, h_til, ws_b, dh)[0].cpu().numpy()
+        pg_a = sb.tconv_bwd(dst_is_var, 16, cp, xs, xd, h_ref, ws_a, dh)[0].cpu().numpy()
+        keep = np.ones(1104, bool)
+        keep[256:272] = False                                   # lin_key.bias
+        close(pg_b[keep], pg_a[keep], 2e-5, "param grads after tiled forward")
+    # whole model with both tiled attention copies attached
+    ptr, idx, val = sb.export(0), sb.export(1), sb.export(2)
+    insts = []
+    for k in range(4):
+        r0, r1 = k * 600, (k + 1) * 600
+        e0, e1 = ptr[r0], ptr[r1]
+        insts.append(LPInstance(f"s{k}", (ptr[r0:r1 + 1] - e0).astype(np.int64), (idx[e0:e1] - k * 1100).astype(np.int32),
+                                val[e0:e1].astype(np.float64), sb.x1[k * 1100:(k + 1) * 1100].cpu().numpy().astype(np.float64),
+                                sb.x2[r0:r1].cpu().numpy().astype(np.float64),
+                                sb.labels[k * 1100:(k + 1) * 1100].cpu().numpy().astype(np.int32)))
+    r = o2.gnn_forward_backward(sd, o2.BatchCSR(insts))
+    loss, logits, grads = sb.loss_step(flat_gpu)
+    close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "logits with tiled attention forward")
+    close(grads.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "grads with tiled attention forward")

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Attention conv forward microbenchmark on the synthetic batch: generic sweep vs LDS-tiled (variant 1).
+usage: python3 tools/bench_conv.py [instances] [reps]"""
+import os, sys
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from mllp_amd.graph import synthetic_batch
+from oracle.pyg_restatement import flatten_state, init_state
+
+n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+b = synthetic_batch(n_inst)
+params = flatten_state(init_state(42, torch.float32)).cuda()
+def timed(fn):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for dst_is_var, off in ((False, 1392), (True, 288)):
+    nd, ns = (b.N, b.M) if dst_is_var else (b.M, b.N)
+    cp = params[off:off + 1104].contiguous()
+    xs = torch.randn(ns, 16, device="cuda"); xd = torch.randn(nd, 16, device="cuda")
+    ws = b.tconv_workspace(dst_is_var, 16)
+    byt = b.nnz * 8 + 4 * (nd + 1) + ns * 64 + nd * 408
+    ms = timed(lambda: b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)); ref = b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws).clone()
+    print(f"dst_is_var={dst_is_var} generic fwd {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s")
+    info = b.enable_tiled(dst_is_var, variant=1)
+    ms = timed(lambda: b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)); got = b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"dst_is_var={dst_is_var} tiled   fwd {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s  ({byt/ms/1e6/8000:.3f} of 8 TB/s) maxrel={err:.2e}  {info}")

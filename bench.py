@@ -26,8 +26,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The library runs each step on two HIP streams; with RCCL's own streams in the process the default of 4 hardware
+# queues makes them share a queue and serialises the pair (measured 1.17 vs 0.98 ms/step).  The HIP runtime reads
+# this when it loads, i.e. at `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -1,0 +1,8 @@
+"""MI355X-native learned-LP hot path of mllp."""
+import os as _os
+
+# Two compute streams per step plus RCCL's streams need more than the HIP runtime's default 4 hardware queues,
+# or the pair gets mapped onto one queue and serialised.  Read by the runtime when it
+# loads, so this only takes effect when the package is imported before torch; bench.py and the experiment driver
+# do that.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -38,7 +38,7 @@ struct Tiled {
     const int* blk_id = nullptr;     // [n_tb]
     const int* ptr2 = nullptr;       // [n_tb * rows_per_tile + 1] offsets of the length-sorted positions
     const int* perm = nullptr;       // [n_tb * rows_per_tile] row of each sorted position
-    const int* ent = nullptr;        // [nnz][2] {col_local, value bits}
+    const int* ent = nullptr;        // [nnz][2] {col_local * 64 (byte offset of the source row in the staged block), value bits}
 };
 
 struct Orient {

@@ -59,12 +59,14 @@ struct TiledDev {
     const int* __restrict__ blk_id;     // [n_tb] global column-block id
     const int* __restrict__ ptr2;       // [n_tb * T_R + 1] entry offsets per (tile-block, sorted position)
     const int* __restrict__ perm;       // [n_tb * T_R] row (inside the tile) of each sorted position
-    const int2* __restrict__ ent;       // [nnz] {col_local, value bits}
+    const int2* __restrict__ ent;       // [nnz] {byte offset of the source row inside the staged block = col_local * 64, value bits}
     int n_tiles, n_dst, n_src;
 };
 
 // ABL: ablation mask for timing-only builds (results wrong when != 0): 1 = no H loads, 2 = no entry loads,
-// 4 = no walk, 8 = no LDS writes of H / entries
+// 4 = no walk, 8 = no LDS writes of H / entries, 16 = instead of the result, row `tile` of Y receives the cycles
+// (s_memtime, summed over the 16 waves) spent in {barrier 1, vmcnt wait + ds_write, barrier 2, prefetch issue,
+// walk, whole kernel}
 template <int ABL>
 __global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 128 VGPRs: no spills
 void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
@@ -110,10 +112,18 @@ void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
     }
 
     // one block: registers -> LDS, refill the register set with block tb + 2, walk
+#define T_TICK(K)                                                                                           \
+    if (ABL & 16) {                                                                                         \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();                                       \
+        cyc[K] += now_ - last_;                                                                             \
+        last_ = now_;                                                                                       \
+    }
 #define T_DO_BLOCK(S, TB)                                                                                   \
     {                                                                                                       \
         const int tbc_ = (TB);                                                                              \
+        T_TICK(4)                                                                                           \
         __syncthreads(); /* every wave is done with the previous block's LDS image */                      \
+        T_TICK(0)                                                                                           \
         Xs[tid] = px##S##0; Xs[tid + T_THREADS] = px##S##1;                                                 \
         Xs[tid + 2 * T_THREADS] = px##S##2; Xs[tid + 3 * T_THREADS] = px##S##3;                             \
         Es[tid] = pe##S##0; Es[tid + T_THREADS] = pe##S##1; Es[tid + 2 * T_THREADS] = pe##S##2;             \
@@ -125,11 +135,16 @@ void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
         }                                                                                                   \
         if (tid == 0) Ps[T_R] = len##S;                                                                     \
         const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
+        T_TICK(1)                                                                                           \
         __syncthreads();                                                                                    \
+        T_TICK(2)                                                                                           \
         const int tb_next = min(tbc_ + 2, tb1 - 1); /* the tail refetches the last block */                \
         if (early) T_PREFETCH(S, tb_next)                                                                   \
+        T_TICK(3)                                                                                           \
         walk(cur_seg0, cur_len);                                                                            \
+        T_TICK(4)                                                                                           \
         if (!early) T_PREFETCH(S, tb_next)                                                                  \
+        T_TICK(3)                                                                                           \
     }
 
     auto walk = [&](int cur_seg0, int cur_len) {
@@ -153,13 +168,13 @@ void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
                     const int pe_ = e - w0;
                     for (; p + 1 < pe_; p += 2) {
                         const int2 e0 = Es[p], e1 = Es[p + 1];
-                        const float4 x0 = Xs[e0.x * 4 + part], x1 = Xs[e1.x * 4 + part];
+                        const float4 x0 = Xs[(e0.x >> 4) + part], x1 = Xs[(e1.x >> 4) + part];
                         fma4(__int_as_float(e0.y), x0, a);
                         fma4(__int_as_float(e1.y), x1, a);
                     }
                     if (p < pe_) {
                         const int2 e0 = Es[p];
-                        fma4(__int_as_float(e0.y), Xs[e0.x * 4 + part], a);
+                        fma4(__int_as_float(e0.y), Xs[(e0.x >> 4) + part], a);
                     }
                     Ya[rl * 4 + part] = a;
                 }
@@ -171,6 +186,9 @@ void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
     int2 peA0, peA1, peA2, peA3, peA4, peA5, peB0, peB1, peB2, peB3, peB4, peB5;
     int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
     const bool early = wave < T_WAVES / 2;   // half of the waves burst their loads before the walk, half after
+    unsigned cyc[5] = {0u, 0u, 0u, 0u, 0u};
+    const unsigned start_ = (ABL & 16) ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    unsigned last_ = start_;
     if (tb0 < tb1) {
         T_PREFETCH(A, tb0)
         T_PREFETCH(B, min(tb0 + 1, tb1 - 1))
@@ -183,7 +201,306 @@ void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
 #undef T_LDE
 #undef T_PREFETCH
 #undef T_DO_BLOCK
+#undef T_TICK
     __syncthreads();
+    if (ABL & 16) {      // timing build: per-phase cycles of this workgroup instead of the result
+        const unsigned total_ = (unsigned)__builtin_amdgcn_s_memtime() - start_;
+        int* acc = reinterpret_cast<int*>(Ps);
+        if (tid < 8) acc[tid] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            for (int k = 0; k < 5; ++k) atomicAdd(&acc[k], (int)cyc[k]);
+            atomicAdd(&acc[5], (int)total_);
+        }
+        __syncthreads();
+        if (tid < 8 && tile < t.n_dst) Y[(size_t)tile * 16 + tid] = (float)acc[tid];
+        return;
+    }
+    const int row0 = tile * T_R;
+    const int n4 = min(T_R, t.n_dst - row0) * 4;
+    float4* dst = reinterpret_cast<float4*>(Y + (size_t)row0 * 16);
+    for (int i = tid; i < n4; i += T_THREADS) dst[i] = Ya[i];
+}
+
+// =================================================================================================
+// Wave-specialised SpMM (the shipped one).  The cycle counters of the version above (tools/phase_cycles.py)
+// showed every wave blocked 21 % of its time while ISSUING its prefetch (the CU's vector-memory path takes
+// 64 B/clk and all 16 waves burst 110 KB per block at once), 30 % in barriers / waiting for loads, and a walk
+// that costs 15 VALU instructions per nonzero.  Here, same geometry (512 rows x 1024 columns):
+//   waves 12..15  ENTRY LOADERS: entries, offsets and perm stream from HBM into two register sets (block b+1
+//             landed, block b+2 in flight); between barrier A (walkers done) and barrier B (image ready) they
+//             write the landed set into LDS and then refill it with block b+3.
+//   waves 8..11   H LOADERS: the 64 KB of H of the next block (L2 hits: the tiles of an instance share them), one
+//             register set, one block of lookahead.  Back-pressure of the memory path stalls only loader waves.
+//   waves 0..7    WALKERS: two pairs of length-sorted bundles each (snake: w and 15 - w), two rows per quad at a
+//             time.  A quad reads FOUR entries of a row with one 8-byte read per lane and shares them with
+//             quad-perm DPP; per nonzero: one add with a DPP source (the stored entry holds the byte offset of the
+//             H row), one DPP broadcast of the value, two packed FMAs = 6.5 VALU instructions.  The walk is bound
+//             by VALU issue: 12 walker waves (768 x 768 geometry, walkers staging H themselves) walked a block no
+//             faster than 8.
+//   entries of a (row, block) run are ordered round-robin over (column mod 4), starting at the slot of the quad
+//             inside its ds_read_b128 lane group (LPBatch.enable_tiled): four quads served in one LDS cycle then
+//             hit four different quarters of the 256-byte bank row.
+// A segment longer than one window is walked as several (block, window) items, each staged like a block; the
+// item count is padded to even so that the entry loaders' two-set loop is straight-line code.
+// =================================================================================================
+constexpr int W_NW = 8;                     // walker waves
+constexpr int W_LT = 256;                   // threads per loader role (4 waves load H, 4 waves load entries)
+constexpr int W_XPT = (T_CB * 4) / W_LT;    // 16 float4 of H per H-loader thread
+constexpr int W_EPT = T_ECAP / W_LT;        // 24 entries per entry-loader thread
+static_assert(W_NW * 64 + 2 * W_LT == T_THREADS && T_R == 2 * W_LT && T_BUNDLES == 4 * W_NW, "role split");
+
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc += v * x on four channels as two packed FMAs (v_pk_fma_f32)
+__device__ __forceinline__ void pk_fma4(float v, const float4& x, f32x2& lo, f32x2& hi) {
+    const f32x2 vv = {v, v};
+    lo = __builtin_elementwise_fma(vv, f32x2{x.x, x.y}, lo);
+    hi = __builtin_elementwise_fma(vv, f32x2{x.z, x.w}, hi);
+}
+// 16 bytes of the staged H image at a byte offset
+__device__ __forceinline__ float4 lds_row(const float4* img, int byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + byte_off);
+}
+
+// ABL: 4 = no walk (timing only), 16 = timing build: instead of the result Y receives cycle counters (s_memtime):
+//   row 2*tile      walkers, summed over waves: [0] wait at A, [1] stage (A..B), [4] walk, [5] total; loaders at [8..]:
+//                   [8] wait at B, [9] vmcnt wait + ds_write, [10] wait at A, [11] load issue, [13] total
+//   row 2*tile + 1  per walker wave: walk cycles [0..7], wait at A [8..15]
+template <int ABL>
+__global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __restrict__ Y) {
+    __shared__ float4 Xs[T_CB * 4];     // 64 KB  staged column block of H
+    __shared__ int2 Es[T_ECAP];         // 48 KB  entry window
+    __shared__ float4 Ya[T_R * 4];      // 32 KB  accumulators of the row tile
+    __shared__ int2 PP[T_R + 8];        // per sorted position {offset inside the segment, row}; [T_R].x = segment length
+    __shared__ int Sg[T_MAXB + 1];      // segment start of every block of this tile
+    __shared__ int Bk[T_MAXB];          // column-block id of every block of this tile
+    __shared__ int n_items_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_tile(blockIdx.x, t.n_tiles);
+    const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
+    const int nb = tb1 - tb0;
+
+    for (int i = tid; i < T_R * 4; i += T_THREADS) Ya[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid <= nb) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * T_R];
+    if (tid < nb) Bk[tid] = t.blk_id[tb0 + tid];
+    if (tid == 0) n_items_s = 0;
+    __syncthreads();
+    if (tid < nb) {
+        const int len = Sg[tid + 1] - Sg[tid];
+        atomicAdd(&n_items_s, max(1, (len + T_ECAP - 1) / T_ECAP));
+    }
+    __syncthreads();
+    const int n_items = n_items_s;
+    const int n_even = (n_items + 1) & ~1;   // every role runs this many stage / barrier rounds
+
+    unsigned cyc[5] = {0u, 0u, 0u, 0u, 0u};
+    const unsigned start_ = (ABL & 16) ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    unsigned last_ = start_;
+#define W_TICK(K)                                                                                           \
+    if (ABL & 16) {                                                                                         \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();                                       \
+        cyc[K] += now_ - last_;                                                                             \
+        last_ = now_;                                                                                       \
+    }
+    // item = (block index inside the tile, window start); all roles step through the same sequence
+#define W_ADVANCE(B, W)                                                                                     \
+    {                                                                                                       \
+        W += T_ECAP;                                                                                        \
+        if (W >= Sg[B + 1] - Sg[B]) { W = 0; B += 1; }                                                      \
+    }
+
+    if (wave >= W_NW + W_LT / 64) {
+        // ------------------------------------------------ entry loaders ------------------------------
+        const int lid = tid - (W_NW * 64 + W_LT);
+        int2 peA0, peA1, peA2, peA3, peA4, peA5, peA6, peA7, peA8, peA9, peA10, peA11, peA12, peA13, peA14, peA15, peA16, peA17, peA18, peA19, peA20, peA21, peA22, peA23;
+        int2 peB0, peB1, peB2, peB3, peB4, peB5, peB6, peB7, peB8, peB9, peB10, peB11, peB12, peB13, peB14, peB15, peB16, peB17, peB18, peB19, peB20, peB21, peB22, peB23;
+        int2 ppA = make_int2(0, 0), pmA = ppA, ppB = ppA, pmB = ppA;
+        int lenA = 0, lenB = 0, segA = 0, segB = 0;
+        static_assert(W_EPT == 24, "the entry-loader macros are written for 24 loads per thread");
+        // (scalar variables, not arrays: arrays indexed in macro loops were demoted to scratch memory)
+#define W_LDE(S, K) pe##S##K = es_[(unsigned)min(lid + K * W_LT, wl_ - 1)];
+#define W_STE(S, K) Es[lid + K * W_LT] = pe##S##K;
+#define W_LOADE(S, B, W)                                                                                    \
+    {                                                                                                       \
+        const int b_ = min((B), nb - 1);                       /* past the end: refetch the last block */  \
+        const int w_ = (B) < nb ? (W) : 0;                                                                  \
+        seg##S = __builtin_amdgcn_readfirstlane(Sg[b_]);                                                    \
+        len##S = __builtin_amdgcn_readfirstlane(Sg[b_ + 1]) - seg##S;                                       \
+        const int wl_ = max(min(T_ECAP, len##S - w_), 1);                                                   \
+        const int2* es_ = t.ent + seg##S + w_;                                                              \
+        /* (offsets are made segment-relative at stage time: touching the loaded value here would wait for it) */ \
+        pp##S = reinterpret_cast<const int2*>(t.ptr2 + (size_t)(tb0 + b_) * T_R)[lid];                      \
+        pm##S = reinterpret_cast<const int2*>(t.perm + (size_t)(tb0 + b_) * T_R)[lid];                      \
+        W_LDE(S, 0) W_LDE(S, 1) W_LDE(S, 2) W_LDE(S, 3)                                                      \
+        W_LDE(S, 4) W_LDE(S, 5) W_LDE(S, 6) W_LDE(S, 7)                                                      \
+        W_LDE(S, 8) W_LDE(S, 9) W_LDE(S, 10) W_LDE(S, 11)                                                    \
+        W_LDE(S, 12) W_LDE(S, 13) W_LDE(S, 14) W_LDE(S, 15)                                                  \
+        W_LDE(S, 16) W_LDE(S, 17) W_LDE(S, 18) W_LDE(S, 19)                                                  \
+        W_LDE(S, 20) W_LDE(S, 21) W_LDE(S, 22) W_LDE(S, 23)                                                  \
+    }
+#define W_STAGEE(S)                                                                                         \
+    {                                                                                                       \
+        W_TICK(3)                                                                                           \
+        __syncthreads();                     /* A: the walkers are done with the previous image */          \
+        W_TICK(2)                                                                                           \
+        W_STE(S, 0) W_STE(S, 1) W_STE(S, 2) W_STE(S, 3)                                                      \
+        W_STE(S, 4) W_STE(S, 5) W_STE(S, 6) W_STE(S, 7)                                                      \
+        W_STE(S, 8) W_STE(S, 9) W_STE(S, 10) W_STE(S, 11)                                                    \
+        W_STE(S, 12) W_STE(S, 13) W_STE(S, 14) W_STE(S, 15)                                                  \
+        W_STE(S, 16) W_STE(S, 17) W_STE(S, 18) W_STE(S, 19)                                                  \
+        W_STE(S, 20) W_STE(S, 21) W_STE(S, 22) W_STE(S, 23)                                                  \
+        reinterpret_cast<int4*>(PP)[lid] = make_int4(pp##S.x - seg##S, pm##S.x, pp##S.y - seg##S, pm##S.y); \
+        if (lid == 0) PP[T_R] = make_int2(len##S, 0);                                                       \
+        W_TICK(1)                                                                                           \
+        __syncthreads();                     /* B: image ready */                                           \
+        W_TICK(0)                                                                                           \
+    }
+        int be = 0, we = 0;          // item whose entries are loaded next
+        W_LOADE(A, be, we)
+        W_ADVANCE(be, we)
+        __builtin_amdgcn_sched_barrier(0);   // keep set A older than set B for the counted vmcnt waits
+        W_LOADE(B, be, we)
+        if (be < nb) W_ADVANCE(be, we)
+        // Straight-line pairs: with an `if` or a `break` between the halves the structurised loop has a path on
+        // which set A is the youngest at the loop top, and the compiler's vmcnt bookkeeping then waits for everything.
+        for (int it = 0; it < n_even; it += 2) {
+            W_STAGEE(A)
+            W_LOADE(A, be, we)
+            if (be < nb) W_ADVANCE(be, we)
+            W_STAGEE(B)
+            W_LOADE(B, be, we)
+            if (be < nb) W_ADVANCE(be, we)
+        }
+#undef W_LDE
+#undef W_STE
+#undef W_LOADE
+#undef W_STAGEE
+    } else if (wave >= W_NW) {
+        // ------------------------------------------------ H loaders ----------------------------------
+        const int lid = tid - W_NW * 64;
+        float4 px0, px1, px2, px3, px4, px5, px6, px7, px8, px9, px10, px11, px12, px13, px14, px15;
+        static_assert(W_XPT == 16, "the H-loader macros are written for 16 loads per thread");
+#define W_LDX(K) px##K = src_[(unsigned)min(lid + K * W_LT, c4_ - 1)];
+#define W_STX(K) Xs[lid + K * W_LT] = px##K;
+#define W_LOADX(B)                                                                                          \
+    {                                                                                                       \
+        const int b_ = min((B), nb - 1);                                                                    \
+        const int c0_ = __builtin_amdgcn_readfirstlane(Bk[b_]) * T_CB;   /* wave-uniform: SGPR base */     \
+        const int c4_ = min(T_CB, t.n_src - c0_) * 4;                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(X + (size_t)c0_ * 16);                        \
+        W_LDX(0) W_LDX(1) W_LDX(2) W_LDX(3)                                                                  \
+        W_LDX(4) W_LDX(5) W_LDX(6) W_LDX(7)                                                                  \
+        W_LDX(8) W_LDX(9) W_LDX(10) W_LDX(11)                                                                \
+        W_LDX(12) W_LDX(13) W_LDX(14) W_LDX(15)                                                              \
+    }
+        int bx = 0, wx = 0;          // item whose H block is loaded next
+        W_LOADX(bx)
+        W_ADVANCE(bx, wx)
+        for (int it = 0; it < n_even; ++it) {
+            W_TICK(3)
+            __syncthreads();                     // A
+            W_TICK(2)
+            W_STX(0) W_STX(1) W_STX(2) W_STX(3)
+            W_STX(4) W_STX(5) W_STX(6) W_STX(7)
+            W_STX(8) W_STX(9) W_STX(10) W_STX(11)
+            W_STX(12) W_STX(13) W_STX(14) W_STX(15)
+            W_TICK(1)
+            __syncthreads();                     // B
+            W_TICK(0)
+            W_LOADX(bx)
+            if (bx < nb) W_ADVANCE(bx, wx)
+        }
+#undef W_LDX
+#undef W_STX
+#undef W_LOADX
+    } else {
+        // ------------------------------------------------ walkers ------------------------------------
+        const int quad = lane >> 2, part = lane & 3, part16 = part * 16;
+        int bi = 0, w0 = 0;          // current item
+        for (int it = 0; it < n_even; ++it) {
+            W_TICK(4)
+            __syncthreads();         // A
+            W_TICK(0)
+            __syncthreads();         // B
+            W_TICK(1)
+            if (it >= n_items) break;            // the padding round of an odd item count: barriers only
+            const int w1 = w0 + T_ECAP;
+            // headers of both passes (offsets, rows, accumulators, first entries) are read up front, so the second
+            // pass starts without dependent LDS round trips.  (Handing the pairs out from an LDS counter, longest
+            // first, was slower and did not shorten the wait at the barrier.)
+            const int k0 = wave * 32 + quad, k1 = (2 * W_NW - 1 - wave) * 32 + quad;
+            const int2 hA0 = PP[k0], hA0n = PP[k0 + 1], hB0 = PP[k0 + 16], hB0n = PP[k0 + 17];
+            const int2 hA1 = PP[k1], hA1n = PP[k1 + 1], hB1 = PP[k1 + 16], hB1n = PP[k1 + 17];
+#define W_ROWS(P)                                                                                           \
+    const int sA##P = max(hA##P.x, w0) - w0, eA##P = min(hA##P##n.x, w1) - w0;                              \
+    const int sB##P = max(hB##P.x, w0) - w0, eB##P = min(hB##P##n.x, w1) - w0;                              \
+    float4 aA##P = Ya[hA##P.y * 4 + part], aB##P = Ya[hB##P.y * 4 + part];                                 \
+    int2 nA##P = Es[min(sA##P + part, T_ECAP - 1)], nB##P = Es[min(sB##P + part, T_ECAP - 1)];
+            W_ROWS(0)
+            W_ROWS(1)
+#undef W_ROWS
+#define W_WALK(P)                                                                                           \
+    if ((sA##P < eA##P || sB##P < eB##P) && !(ABL & 4)) {                                                   \
+        const int n_it = max(eA##P - sA##P, eB##P - sB##P);                                                 \
+        f32x2 cA0 = {aA##P.x, aA##P.y}, cA1 = {aA##P.z, aA##P.w};                                           \
+        f32x2 cB0 = {aB##P.x, aB##P.y}, cB1 = {aB##P.z, aB##P.w};                                           \
+        int2 nA = nA##P, nB = nB##P;                                                                        \
+        for (int j = 0; j < n_it; j += 4) {                                                                 \
+            /* four entries of each row, one per lane of the quad; lanes past the end contribute 0 * H[0] */ \
+            const int2 mA = nA, mB = nB;                                                                    \
+            const int pA = sA##P + j + part, pB = sB##P + j + part;                                         \
+            nA = Es[min(pA + 4, T_ECAP - 1)];                                                               \
+            nB = Es[min(pB + 4, T_ECAP - 1)];                                                               \
+            const int colA = pA < eA##P ? mA.x : 0, valA = pA < eA##P ? mA.y : 0;                           \
+            const int colB = pB < eB##P ? mB.x : 0, valB = pB < eB##P ? mB.y : 0;                           \
+            const float4 x0 = lds_row(Xs, quad_bcast<0>(colA) + part16), x1 = lds_row(Xs, quad_bcast<1>(colA) + part16), \
+                         x2 = lds_row(Xs, quad_bcast<2>(colA) + part16), x3 = lds_row(Xs, quad_bcast<3>(colA) + part16); \
+            const float4 y0 = lds_row(Xs, quad_bcast<0>(colB) + part16), y1 = lds_row(Xs, quad_bcast<1>(colB) + part16), \
+                         y2 = lds_row(Xs, quad_bcast<2>(colB) + part16), y3 = lds_row(Xs, quad_bcast<3>(colB) + part16); \
+            pk_fma4(__int_as_float(quad_bcast<0>(valA)), x0, cA0, cA1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<1>(valA)), x1, cA0, cA1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<2>(valA)), x2, cA0, cA1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<3>(valA)), x3, cA0, cA1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<0>(valB)), y0, cB0, cB1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<1>(valB)), y1, cB0, cB1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<2>(valB)), y2, cB0, cB1);                                     \
+            pk_fma4(__int_as_float(quad_bcast<3>(valB)), y3, cB0, cB1);                                     \
+        }                                                                                                   \
+        Ya[hA##P.y * 4 + part] = make_float4(cA0.x, cA0.y, cA1.x, cA1.y);                                   \
+        Ya[hB##P.y * 4 + part] = make_float4(cB0.x, cB0.y, cB1.x, cB1.y);                                   \
+    }
+            W_WALK(0)
+            W_WALK(1)
+#undef W_WALK
+            W_ADVANCE(bi, w0)
+        }
+    }
+#undef W_ADVANCE
+    __syncthreads();
+    if (ABL & 16) {
+        const unsigned total_ = (unsigned)__builtin_amdgcn_s_memtime() - start_;
+        int* acc = reinterpret_cast<int*>(PP);
+        if (tid < 16) acc[tid] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            const int o = wave >= W_NW ? 8 : 0;
+            for (int k = 0; k < 5; ++k) atomicAdd(&acc[o + k], (int)cyc[k]);
+            atomicAdd(&acc[o + 5], (int)total_);
+        }
+        __syncthreads();
+        if (tid < 16 && 2 * tile + 1 < t.n_dst) Y[(size_t)(2 * tile) * 16 + tid] = (float)acc[tid];
+        if (lane == 0 && wave < W_NW && 2 * tile + 1 < t.n_dst) {
+            Y[(size_t)(2 * tile + 1) * 16 + wave] = (float)cyc[4];
+            Y[(size_t)(2 * tile + 1) * 16 + 8 + wave] = (float)cyc[0];
+        }
+        return;
+    }
+#undef W_TICK
     const int row0 = tile * T_R;
     const int n4 = min(T_R, t.n_dst - row0) * 4;
     float4* dst = reinterpret_cast<float4*>(Y + (size_t)row0 * 16);
@@ -301,7 +618,7 @@ __global__ __launch_bounds__(T_THREADS) void fwd16_tiled_kernel(TiledDev t, FwdT
                     const int pe_ = e - w0;
                     for (; p + 1 < pe_; p += 2) {      // two entries per pass: their LDS reads and dot products are independent
                         const int2 e0 = Es[p], e1 = Es[p + 1];
-                        const float4 x0 = Xs[e0.x * 4 + part], x1 = Xs[e1.x * 4 + part];
+                        const float4 x0 = Xs[(e0.x >> 4) + part], x1 = Xs[(e1.x >> 4) + part];
                         const float a0 = __int_as_float(e0.y), a1 = __int_as_float(e1.y);
                         const float d0 = fmaf(a0, tq, quad_sum4(dot4(q, x0)));
                         const float d1 = fmaf(a1, tq, quad_sum4(dot4(q, x1)));
@@ -321,7 +638,7 @@ __global__ __launch_bounds__(T_THREADS) void fwd16_tiled_kernel(TiledDev t, FwdT
                     }
                     if (p < pe_) {
                         const int2 en = Es[p];
-                        const float4 x = Xs[en.x * 4 + part];
+                        const float4 x = Xs[(en.x >> 4) + part];
                         const float av = __int_as_float(en.y);
                         const float d = fmaf(av, tq, quad_sum4(dot4(q, x)));
                         if (__any(d > m)) {
@@ -409,12 +726,28 @@ static int g_tiled_ablation = [] {
     return e ? atoi(e) : 0;
 }();
 
+// MLLP_TILED_SPMM=v1 selects the previous (all waves load and walk) kernel for A/B timing
+static int g_tiled_ws = [] {
+    const char* e = getenv("MLLP_TILED_SPMM");
+    return (e && e[0] == 'v' && e[1] == '1') ? 0 : 1;
+}();
+
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s) {
     if (tl.n_tiles == 0) return MLLP_OK;
     TiledDev d;
     d.tile_blk = tl.tile_blk; d.blk_id = tl.blk_id; d.ptr2 = tl.ptr2; d.perm = tl.perm;
     d.ent = reinterpret_cast<const int2*>(tl.ent);
     d.n_tiles = tl.n_tiles; d.n_dst = n_dst; d.n_src = n_src;
+    if (g_tiled_ws) {
+        switch (g_tiled_ablation) {
+            case 0: hipLaunchKernelGGL(spmm_tiled_ws_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+            case 4: hipLaunchKernelGGL(spmm_tiled_ws_kernel<4>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+            case 16: hipLaunchKernelGGL(spmm_tiled_ws_kernel<16>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+            default: return fail(MLLP_EINVAL, "unknown ablation mask");
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled_ws");
+    }
     switch (g_tiled_ablation) {
         case 0: hipLaunchKernelGGL(spmm_tiled_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         case 1: hipLaunchKernelGGL(spmm_tiled_kernel<1>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
@@ -422,6 +755,7 @@ int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, flo
         case 3: hipLaunchKernelGGL(spmm_tiled_kernel<3>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         case 4: hipLaunchKernelGGL(spmm_tiled_kernel<4>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         case 7: hipLaunchKernelGGL(spmm_tiled_kernel<7>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+        case 16: hipLaunchKernelGGL(spmm_tiled_kernel<16>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         case 12: hipLaunchKernelGGL(spmm_tiled_kernel<12>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         default: return fail(MLLP_EINVAL, "unknown ablation mask");
     }
@@ -432,7 +766,7 @@ int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, flo
 int tiled_max_blocks_per_tile() { return T_MAXB; }
 
 int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bundle_capacity) {
-    if (variant == 0) {          // plain SpMM
+    if (variant == 0) {          // plain SpMM (both kernels)
         *rows_per_tile = T_R; *cols_per_block = T_CB; *bundle_capacity = T_ECAP;
     } else {                     // attention sweeps
         *rows_per_tile = F_R; *cols_per_block = F_CB; *bundle_capacity = F_ECAP;

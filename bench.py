@@ -221,7 +221,24 @@ def main():
             kernels.append({"kernel": "tconv_fwd16 LDS-tiled (prep + node_qp + fwd16_tiled_kernel), dst=constraints",
                             "ms": ms_ft, "alg_bytes": b_f, "GBps": b_f / ms_ft / 1e6,
                             "frac": b_f / ms_ft / 1e6 / HBM_PEAK_GBS})
-        del ws, h, Hm
+        # one attention conv backward (bwd_pre + destination-major sweep + source-major sweep + parameter statistics):
+        # generic gathers, then with the LDS-tiled source-major sweep (variant 2 copy on the orientation whose rows are
+        # the conv's sources).  Bytes: two pattern sweeps + node tensors
+        dh = torch.randn(sb.M, 16, device="cuda")
+        b_b = 16 * sb.nnz + 192 * sb.N + 1216 * sb.M
+
+        def conv_b():
+            sb.tconv_bwd(False, 16, cp, Hn, Hm, h[0], ws, dh)
+        conv_f()
+        ms_bg = timed(conv_b, 3, warm=1)
+        kernels.append({"kernel": "tconv_bwd16 generic (bwd_pre + dst sweep + src gather sweep + stats), dst=constraints",
+                        "ms": ms_bg, "alg_bytes": b_b, "GBps": b_b / ms_bg / 1e6, "frac": b_b / ms_bg / 1e6 / HBM_PEAK_GBS})
+        if sb.enable_tiled(True, variant=2) and sb.enable_tiled(False, variant=2):
+            ms_bt = timed(conv_b, 3, warm=1)
+            kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel, dst=constraints",
+                            "ms": ms_bt, "alg_bytes": b_b, "GBps": b_b / ms_bt / 1e6,
+                            "frac": b_b / ms_bt / 1e6 / HBM_PEAK_GBS})
+        del ws, h, Hm, dh
         out["roofline"] = {"bound": "hbm", "kernel": "spmm_tiled_kernel (plain CSR SpMM, Y = A*H, C=16, fp32, LDS-tiled)",
                            "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
                                        f"nnz={sb.nnz}", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s",

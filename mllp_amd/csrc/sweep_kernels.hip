@@ -766,6 +766,9 @@ int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, cons
 
 int launch_attn_bwd_src(const Orient& o_src_major, const ConvWs& w, const float* x_src, float* dx_src, int accumulate,
                         float* scratch, hipStream_t s) {
+    if (o_src_major.tiled_bsrc.n_tiles > 0)
+        return launch_bwdsrc16_tiled(o_src_major.tiled_bsrc, o_src_major.n_dst, o_src_major.n_src, w.rec, x_src, dx_src,
+                                     accumulate, s);
     BwdSrcArgs a{x_src, w.rec, dx_src, accumulate};
     return launch_sweep<BwdSrc16Op, 2, 2>(o_src_major, a, scratch, s, "attn_bwd_src16");
 }

@@ -720,6 +720,178 @@ int launch_fwd16_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "fwd16_tiled");
 }
 
+// =================================================================================================
+// Attention backward, source-major, in the tiled form: dX_j = sum_i alpha_ij gv_i + dl_ij q'_i.
+// Rows of this sweep are SOURCE nodes j (the orientation opposite to the conv's destination-major one); the
+// column blocks hold the 160-byte backward RECORDS of the destination nodes {q'[16], gv[16], t, rowmax, 1/rowsum,
+// ge, c}.  The generic sweep gathers 148 bytes per nonzero from L2 (the largest item of the training step on the
+// synthetic batch); here a block of 384 records (60 KB, contiguous in memory) is staged in LDS, and the tile keeps
+// x_j and the running dX_j of its 512 rows in LDS.  Geometry (variant 2): 512 rows x 384 columns, 3072-entry
+// windows.  Per nonzero a quad recomputes the logit (4 FMAs + DPP quad sum), alpha, dl (second dot product) and
+// adds alpha gv + dl q' (8 FMAs).  Same staging scheme as the attention forward kernel above.
+// =================================================================================================
+constexpr int S_R = 512;
+constexpr int S_BUNDLES = S_R / 16;
+constexpr int S_CB = 384;
+constexpr int S_ECAP = 3 * T_THREADS;      // 3072 entries (24 KB) per window
+constexpr int S_REC4 = REC_W / 4;          // float4 per record
+static_assert(REC_W == 40, "record layout: q'[16] gv[16] {t, rowmax, rinv, ge} c ...");
+static_assert(S_CB * S_REC4 <= 4 * T_THREADS, "record block staged with 4 float4 per thread");
+
+struct BwdSrcTiledArgs {
+    const float* __restrict__ X;        // [n_rows, 16] features of the source nodes (rows of this sweep)
+    const float* __restrict__ rec;      // [n_cols, REC_W] backward records of the destination nodes
+    float* __restrict__ dX;             // [n_rows, 16]
+    int accumulate;
+};
+
+__global__ __launch_bounds__(T_THREADS) void bwdsrc16_tiled_kernel(TiledDev t, BwdSrcTiledArgs a) {
+    __shared__ float4 Rs[S_CB * S_REC4];    // 60 KB  staged records of the column block
+    __shared__ int2 Es[S_ECAP];             // 24 KB  entry segment (window): {record byte offset, value bits}
+    __shared__ float4 Xj[S_R * 4];          // 32 KB  x_j of the tile's rows
+    __shared__ float4 Ac[S_R * 4];          // 32 KB  running dX_j
+    __shared__ int Ps[S_R + 16];
+    __shared__ int Pm[S_R];
+    __shared__ int Sg[T_MAXB + 1];
+    __shared__ int Bk[T_MAXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = lane >> 2, part = lane & 3;
+    const int tile = xcd_tile(blockIdx.x, t.n_tiles);
+    const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
+    const int row0 = tile * S_R;
+    const int n_rows = min(S_R, t.n_dst - row0);
+
+    for (int i = tid; i < S_R * 4; i += T_THREADS) {
+        Xj[i] = (i >> 2) < n_rows ? reinterpret_cast<const float4*>(a.X + (size_t)row0 * 16)[i]
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        Ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid <= tb1 - tb0) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * S_R];
+    if (tid < tb1 - tb0) Bk[tid] = t.blk_id[tb0 + tid];
+    __syncthreads();
+
+#define S_PREFETCH(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbx_ = (TB);                                                                              \
+        const int c0_ = Bk[tbx_ - tb0] * S_CB;                                                              \
+        const int c4_ = min(S_CB, t.n_src - c0_) * S_REC4;                                                  \
+        const float4* src_ = reinterpret_cast<const float4*>(a.rec + (size_t)c0_ * REC_W);                 \
+        pr##S##0 = src_[min(tid, c4_ - 1)];                                                                 \
+        pr##S##1 = src_[min(tid + T_THREADS, c4_ - 1)];                                                     \
+        pr##S##2 = src_[min(tid + 2 * T_THREADS, c4_ - 1)];                                                 \
+        pr##S##3 = src_[min(tid + 3 * T_THREADS, c4_ - 1)];                                                 \
+        seg0##S = Sg[tbx_ - tb0];                                                                           \
+        len##S = Sg[tbx_ - tb0 + 1] - seg0##S;                                                              \
+        pp##S = t.ptr2[(size_t)tbx_ * S_R + min(tid, S_R - 1)] - seg0##S;                                   \
+        pm##S = t.perm[(size_t)tbx_ * S_R + min(tid, S_R - 1)];                                             \
+        pe##S##0 = t.ent[seg0##S + min(tid, max(len##S - 1, 0))];                                           \
+        pe##S##1 = t.ent[seg0##S + min(tid + T_THREADS, max(len##S - 1, 0))];                               \
+        pe##S##2 = t.ent[seg0##S + min(tid + 2 * T_THREADS, max(len##S - 1, 0))];                           \
+    }
+#define S_DO_BLOCK(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbc_ = (TB);                                                                              \
+        __syncthreads();                                                                                    \
+        Rs[tid] = pr##S##0; Rs[tid + T_THREADS] = pr##S##1; Rs[tid + 2 * T_THREADS] = pr##S##2;             \
+        if (tid + 3 * T_THREADS < S_CB * S_REC4) Rs[tid + 3 * T_THREADS] = pr##S##3;                        \
+        Es[tid] = pe##S##0; Es[tid + T_THREADS] = pe##S##1; Es[tid + 2 * T_THREADS] = pe##S##2;             \
+        if (tid < S_R) {                                                                                    \
+            Ps[tid] = pp##S;                                                                                \
+            Pm[tid] = pm##S;                                                                                \
+        }                                                                                                   \
+        if (tid == 0) Ps[S_R] = len##S;                                                                     \
+        const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
+        __syncthreads();                                                                                    \
+        const int tb_next = min(tbc_ + 2, tb1 - 1);                                                         \
+        if (early) S_PREFETCH(S, tb_next)                                                                   \
+        walk(cur_seg0, cur_len);                                                                            \
+        if (!early) S_PREFETCH(S, tb_next)                                                                  \
+    }
+
+    // one nonzero of row j against the staged record at byte offset `off`
+    auto edge = [&](int off, float av, const float4& xj, float4& acc) {
+        const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Rs) + off);
+        const float4 qp = r[part], gv = r[4 + part], s0 = r[8];       // s0 = {t, rowmax, rinv, ge}
+        const float cc = reinterpret_cast<const float*>(r)[36];
+        const float l = fmaf(av, s0.x, quad_sum4(dot4(qp, xj)));
+        const float alpha = exp_acc_t(l - s0.y) * s0.z;
+        const float dl = alpha * (quad_sum4(dot4(gv, xj)) + fmaf(av, s0.w, cc));
+        fma4(alpha, gv, acc);
+        fma4(dl, qp, acc);
+    };
+    auto walk = [&](int cur_seg0, int cur_len) {
+        for (int w0 = 0; w0 < cur_len; w0 += S_ECAP) {
+            if (w0 > 0) {   // rare: segment longer than one window
+                __syncthreads();
+                for (int i = tid; i < min(S_ECAP, cur_len - w0); i += T_THREADS) Es[i] = t.ent[cur_seg0 + w0 + i];
+                __syncthreads();
+            }
+            const int w1 = w0 + S_ECAP;
+#pragma unroll
+            for (int pass = 0; pass < S_BUNDLES / T_WAVES; ++pass) {
+                const int bundle = (pass & 1) ? (pass + 1) * T_WAVES - 1 - wave : pass * T_WAVES + wave;
+                const int k = bundle * 16 + quad;
+                const int s = max(Ps[k], w0), e = min(Ps[k + 1], w1);
+                if (s < e) {
+                    const int rl = Pm[k];
+                    const float4 xj = Xj[rl * 4 + part];
+                    float4 acc = Ac[rl * 4 + part];
+                    int p = s - w0;
+                    const int pe_ = e - w0;
+                    for (; p + 1 < pe_; p += 2) {      // two entries per pass: independent LDS reads and dot products
+                        const int2 e0 = Es[p], e1 = Es[p + 1];
+                        edge(e0.x, __int_as_float(e0.y), xj, acc);
+                        edge(e1.x, __int_as_float(e1.y), xj, acc);
+                    }
+                    if (p < pe_) {
+                        const int2 e0 = Es[p];
+                        edge(e0.x, __int_as_float(e0.y), xj, acc);
+                    }
+                    Ac[rl * 4 + part] = acc;
+                }
+            }
+        }
+    };
+
+    float4 prA0, prA1, prA2, prA3, prB0, prB1, prB2, prB3;
+    int2 peA0, peA1, peA2, peB0, peB1, peB2;
+    int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
+    const bool early = wave < T_WAVES / 2;
+    if (tb0 < tb1) {
+        S_PREFETCH(A, tb0)
+        S_PREFETCH(B, min(tb0 + 1, tb1 - 1))
+    }
+    for (int tb = tb0; tb < tb1; tb += 2) {
+        S_DO_BLOCK(A, tb)
+        if (tb + 1 < tb1) S_DO_BLOCK(B, tb + 1)
+    }
+#undef S_PREFETCH
+#undef S_DO_BLOCK
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(a.dX + (size_t)row0 * 16);
+    for (int i = tid; i < n_rows * 4; i += T_THREADS) {
+        float4 v = Ac[i];
+        if (a.accumulate) {
+            const float4 old = dst[i];
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        dst[i] = v;
+    }
+}
+
+int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* rec, const float* x_rows, float* dx,
+                          int accumulate, hipStream_t s) {
+    if (tl.n_tiles == 0) return MLLP_OK;
+    TiledDev d;
+    d.tile_blk = tl.tile_blk; d.blk_id = tl.blk_id; d.ptr2 = tl.ptr2; d.perm = tl.perm;
+    d.ent = reinterpret_cast<const int2*>(tl.ent);
+    d.n_tiles = tl.n_tiles; d.n_dst = n_rows; d.n_src = n_cols;
+    BwdSrcTiledArgs a{x_rows, rec, dx, accumulate};
+    hipLaunchKernelGGL(bwdsrc16_tiled_kernel, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwdsrc16_tiled");
+}
+
 // timing-only ablation switch (MLLP_TILED_ABLATION environment variable; 0 in production)
 static int g_tiled_ablation = [] {
     const char* e = getenv("MLLP_TILED_ABLATION");
@@ -768,8 +940,10 @@ int tiled_max_blocks_per_tile() { return T_MAXB; }
 int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bundle_capacity) {
     if (variant == 0) {          // plain SpMM (both kernels)
         *rows_per_tile = T_R; *cols_per_block = T_CB; *bundle_capacity = T_ECAP;
-    } else {                     // attention sweeps
+    } else if (variant == 1) {   // attention forward sweep
         *rows_per_tile = F_R; *cols_per_block = F_CB; *bundle_capacity = F_ECAP;
+    } else {                     // attention backward, source-major: columns are 160-byte records
+        *rows_per_tile = S_R; *cols_per_block = S_CB; *bundle_capacity = S_ECAP;
     }
     return MLLP_OK;
 }

@@ -157,7 +157,8 @@ class LPBatch:
         dest = ptr2[pos_key] + (new_off - start_idx)
         del ar, start_idx, pos_key, new_off
         ent = torch.empty((nnz, 2), dtype=torch.int32, device=dev)
-        ent[dest, 0] = (idx - blk * CB) * 64       # byte offset of the source row inside the staged block
+        # byte offset of the column's staged item inside the block: 64-byte feature rows, or 160-byte backward records (variant 2)
+        ent[dest, 0] = (idx - blk * CB) * (160 if variant == 2 else 64)
         ent[dest, 1] = val.view(torch.int32)
         del dest, blk
         perm = order.reshape(-1).to(torch.int32).contiguous()

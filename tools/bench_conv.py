@@ -31,3 +31,12 @@ for dst_is_var, off in ((False, 1392), (True, 288)):
     ms = timed(lambda: b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)); got = b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"dst_is_var={dst_is_var} tiled   fwd {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s  ({byt/ms/1e6/8000:.3f} of 8 TB/s) maxrel={err:.2e}  {info}")
+    # backward: generic source-major gather sweep vs LDS-tiled (variant 2, attached to the orientation whose rows are the sources)
+    h = b.tconv_fwd(dst_is_var, 16, cp, xs, xd, ws)
+    dh = torch.randn(nd, 16, device="cuda")
+    ms_g = timed(lambda: b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)); ref = b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)[2].clone()
+    info = b.enable_tiled(not dst_is_var, variant=2)
+    ms_t = timed(lambda: b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)); got = b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)[2]
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"dst_is_var={dst_is_var} conv bwd (all kernels) generic {ms_g:.3f} ms, with tiled source sweep {ms_t:.3f} ms  maxrel={err:.2e}  {info}")
+    b.disable_tiled(not dst_is_var, variant=2); b.disable_tiled(dst_is_var, variant=1)

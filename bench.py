@@ -239,6 +239,20 @@ def main():
                             "ms": ms_bt, "alg_bytes": b_b, "GBps": b_b / ms_bt / 1e6,
                             "frac": b_b / ms_bt / 1e6 / HBM_PEAK_GBS})
         del ws, h, Hm, dh
+        # layer-1 (one channel) conv: generic sweeps, then the LDS-tiled lane-per-row kernels (variant 3)
+        cp1 = params0[144:288].contiguous()
+        x1s, x1d = torch.randn(sb.N, device="cuda"), torch.randn(sb.M, device="cuda")
+        ws1 = sb.tconv_workspace(False, 1)
+        b_f1 = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 4 + sb.M * (4 + 64 + 4 + 16)
+        ms_1g = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 3, warm=1)
+        kernels.append({"kernel": "tconv_fwd1 generic (lane per nonzero, 4-byte gathers from L2), dst=constraints",
+                        "ms": ms_1g, "alg_bytes": b_f1, "GBps": b_f1 / ms_1g / 1e6, "frac": b_f1 / ms_1g / 1e6 / HBM_PEAK_GBS})
+        if sb.enable_tiled(False, variant=3) and sb.enable_tiled(True, variant=3):
+            ms_1t = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 3, warm=1)
+            kernels.append({"kernel": "tconv_fwd1 LDS-tiled (scalar_tiled_kernel, lane per row), dst=constraints",
+                            "ms": ms_1t, "alg_bytes": b_f1, "GBps": b_f1 / ms_1t / 1e6,
+                            "frac": b_f1 / ms_1t / 1e6 / HBM_PEAK_GBS})
+        del ws1, x1s, x1d
         out["roofline"] = {"bound": "hbm", "kernel": "spmm_tiled_kernel (plain CSR SpMM, Y = A*H, C=16, fp32, LDS-tiled)",
                            "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
                                        f"nnz={sb.nnz}", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -892,6 +892,301 @@ int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* 
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwdsrc16_tiled");
 }
 
+// =================================================================================================
+// Layer-1 attention sweeps (scalar node features, reference linear_program_methods.py:90-91, 241-242) in the
+// tiled form.  The generic sweeps gather one 4-byte x_j per nonzero and lane from L2 (one request per nonzero:
+// 4.4 ms forward, 3.1 ms backward at 512 M nonzeros).  With one channel a column block of 1024 sources is only
+// 4 KB, so the workgroup is small: 256 threads = one 256-row tile, ~40 KB of LDS, four workgroups per CU that
+// overlap each other's staging and walking.  ONE LANE PER ROW: a lane walks the entries of its length-sorted row
+// (entry: ds_read_b64, x_j: ds_read_b32, a handful of FMAs, one exp) with no cross-lane traffic at all; wave w
+// takes sorted positions 64w .. 64w+63, i.e. rows of nearly equal length.  Geometry (variant 3): 256 rows x 1024
+// columns, 3072-entry windows; entries {byte offset of x_j in the block = 4 * local column, value}.
+// =================================================================================================
+constexpr int C_THREADS = 256;
+constexpr int C_R = 256;
+constexpr int C_CB = 1024;
+constexpr int C_ECAP = 12 * C_THREADS;     // 3072 entries (24 KB) per window
+
+struct Fwd1TiledArgs {
+    const float* __restrict__ X;        // [n_src]
+    const float* __restrict__ xd;       // [n_dst]
+    const float* __restrict__ derived;
+    ConvParams p;
+    float* __restrict__ h;              // [n_dst, 16]
+    float* __restrict__ Z;              // [n_dst]
+    float* __restrict__ aux;            // [n_dst, 4]
+};
+struct BwdDst1TiledArgs {
+    const float* __restrict__ X;        // [n_src]
+    const float* __restrict__ rec;      // [n_dst, 8] {q', gv, t, rowmax, rinv, ge, c, 0}
+    float* __restrict__ dqp;            // [n_dst]
+    float* __restrict__ dsdt;           // [n_dst, 2]
+};
+
+// forward: per row {rowmax, L, u, Z} and {q', t}
+struct Fwd1T {
+    using Args = Fwd1TiledArgs;
+    float4 st;      // m, L, u, Z
+    float qp, t;
+    __device__ __forceinline__ static void init_row(const Args& a, int row, bool valid, float4* S0, float4* S1) {
+        const float* D = a.derived;
+        const float x = valid ? a.xd[row] : 0.0f;
+        *S0 = make_float4(NEG_BIG, 0.f, 0.f, 0.f);
+        *S1 = make_float4(fmaf(D[OFF_PQ], x, D[OFF_PQ0]), fmaf(D[OFF_PT], x, D[OFF_PT0]), x, 0.f);
+    }
+    __device__ __forceinline__ void load(const float4& s0, const float4& s1) { st = s0; qp = s1.x; t = s1.y; }
+    __device__ __forceinline__ void edge2(float x0, float a0, float x1, float a1) {
+        const float d0 = fmaf(qp, x0, a0 * t), d1 = fmaf(qp, x1, a1 * t);
+        const float dm = fmaxf(d0, d1);
+        if (__any(dm > st.x)) {             // some row of this wave moves its max: rescale those rows
+            const float mn = fmaxf(st.x, dm);
+            const float sc = exp_acc_t(st.x - mn);
+            st.y *= sc; st.z *= sc; st.w *= sc;
+            st.x = mn;
+        }
+        const float p0 = exp_acc_t(d0 - st.x), p1 = exp_acc_t(d1 - st.x);
+        st.y += p0 + p1;
+        st.z = fmaf(p0, a0, fmaf(p1, a1, st.z));
+        st.w = fmaf(p0, x0, fmaf(p1, x1, st.w));
+    }
+    __device__ __forceinline__ void edge1(float x0, float a0) {
+        const float d0 = fmaf(qp, x0, a0 * t);
+        if (__any(d0 > st.x)) {
+            const float mn = fmaxf(st.x, d0);
+            const float sc = exp_acc_t(st.x - mn);
+            st.y *= sc; st.z *= sc; st.w *= sc;
+            st.x = mn;
+        }
+        const float p0 = exp_acc_t(d0 - st.x);
+        st.y += p0;
+        st.z = fmaf(p0, a0, st.z);
+        st.w = fmaf(p0, x0, st.w);
+    }
+    __device__ __forceinline__ void store(float4* s0) const { *s0 = st; }
+    // o = relu(Wv Z + S bv + u we + Ws x + bs), Z, aux                      (sweep_kernels.hip::Fwd1Op::epilogue)
+    __device__ __forceinline__ static void epilogue(const Args& a, int row, const float4& s0, const float4& s1) {
+        const float rinv = 1.0f / (s0.y + 1e-16f);
+        const float S = s0.y * rinv, un = s0.z * rinv, zn = s0.w * rinv;
+        const float x = s1.z;
+        float o[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = a.p.bs[c];
+            v = fmaf(S, a.p.bv[c], v);
+            v = fmaf(un, a.p.we[c], v);
+            v = fmaf(a.p.Wv[c], zn, v);
+            v = fmaf(a.p.Ws[c], x, v);
+            o[c] = fmaxf(v, 0.0f);
+        }
+        float4* hd = reinterpret_cast<float4*>(a.h + (size_t)row * 16);
+        hd[0] = make_float4(o[0], o[1], o[2], o[3]);
+        hd[1] = make_float4(o[4], o[5], o[6], o[7]);
+        hd[2] = make_float4(o[8], o[9], o[10], o[11]);
+        hd[3] = make_float4(o[12], o[13], o[14], o[15]);
+        a.Z[row] = zn;
+        reinterpret_cast<float4*>(a.aux)[row] = make_float4(un, s0.y > 0.0f ? s0.x : 0.0f, rinv, S);
+    }
+};
+
+// backward, destination-major: ds_i, dt_i, dq'_i                             (sweep_kernels.hip::BwdDst1Op)
+struct BwdDst1T {
+    using Args = BwdDst1TiledArgs;
+    float4 acc;     // ds, dt, dqp, -
+    float qp, gv, t, m, rinv, ge, cc;
+    __device__ __forceinline__ static void init_row(const Args& a, int row, bool valid, float4* S0, float4* S1) {
+        // S0 = accumulators, S1 = {q', gv, t, rowmax}; {rinv, ge, c} ride in a third table
+        *S0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        *S1 = valid ? ld4(a.rec + (size_t)row * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ static float4 init_row2(const Args& a, int row, bool valid) {
+        return valid ? ld4(a.rec + (size_t)row * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void load(const float4& s0, const float4& s1, const float4& s2) {
+        acc = s0; qp = s1.x; gv = s1.y; t = s1.z; m = s1.w; rinv = s2.x; ge = s2.y; cc = s2.z;
+    }
+    __device__ __forceinline__ void edge1(float x0, float a0) {
+        const float l = fmaf(qp, x0, a0 * t);
+        const float alpha = exp_acc_t(l - m) * rinv;
+        const float dl = alpha * fmaf(gv, x0, fmaf(a0, ge, cc));
+        acc.x += dl;
+        acc.y = fmaf(dl, a0, acc.y);
+        acc.z = fmaf(dl, x0, acc.z);
+    }
+    __device__ __forceinline__ void store(float4* s0) const { *s0 = acc; }
+    __device__ __forceinline__ static void epilogue(const Args& a, int row, const float4& s0) {
+        a.dqp[row] = s0.z;
+        reinterpret_cast<float2*>(a.dsdt)[row] = make_float2(s0.x, s0.y);
+    }
+};
+
+template <bool BWD, class Args>
+__global__ __launch_bounds__(C_THREADS) void scalar_tiled_kernel(TiledDev t, Args a) {
+    __shared__ float Xs[C_CB];              //  4 KB  staged x_j of the column block
+    __shared__ int2 Es[C_ECAP];             // 24 KB  entry segment (window)
+    __shared__ float4 S0[C_R];              //  4 KB  running state of the rows
+    __shared__ float4 S1[C_R];              //  4 KB  per-row inputs
+    __shared__ float4 S2[BWD ? C_R : 1];    //  4 KB  (backward only)
+    __shared__ int Ps[C_R + 16];
+    __shared__ int Pm[C_R];
+    __shared__ int Sg[T_MAXB + 1];
+    __shared__ int Bk[T_MAXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_tile(blockIdx.x, t.n_tiles);
+    const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
+    const int row0 = tile * C_R;
+    const int n_rows = min(C_R, t.n_dst - row0);
+    (void)lane;
+
+    if constexpr (BWD) {
+        BwdDst1T::init_row(a, row0 + tid, tid < n_rows, &S0[tid], &S1[tid]);
+        S2[tid] = BwdDst1T::init_row2(a, row0 + tid, tid < n_rows);
+    } else {
+        Fwd1T::init_row(a, row0 + tid, tid < n_rows, &S0[tid], &S1[tid]);
+    }
+    if (tid <= tb1 - tb0) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * C_R];
+    if (tid < tb1 - tb0) Bk[tid] = t.blk_id[tb0 + tid];
+    __syncthreads();
+
+#define C_LDE(S, K) pe##S##K = t.ent[seg0##S + min(tid + K * C_THREADS, max(len##S - 1, 0))];
+#define C_STE(S, K) Es[tid + K * C_THREADS] = pe##S##K;
+#define C_PREFETCH(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbx_ = (TB);                                                                              \
+        const int c0_ = Bk[tbx_ - tb0] * C_CB;                                                              \
+        const int c4_ = (min(C_CB, t.n_src - c0_) + 3) / 4;                                                 \
+        /* (the last block of x may end inside a float4: the tail is read element-wise) */                 \
+        const float* src_ = a.X + c0_;                                                                      \
+        const int i4_ = min(tid, c4_ - 1) * 4;                                                              \
+        const int lim_ = t.n_src - c0_ - 1;                                                                 \
+        px##S = make_float4(src_[min(i4_, lim_)], src_[min(i4_ + 1, lim_)], src_[min(i4_ + 2, lim_)],       \
+                            src_[min(i4_ + 3, lim_)]);                                                      \
+        seg0##S = Sg[tbx_ - tb0];                                                                           \
+        len##S = Sg[tbx_ - tb0 + 1] - seg0##S;                                                              \
+        pp##S = t.ptr2[(size_t)tbx_ * C_R + tid] - seg0##S;                                                 \
+        pm##S = t.perm[(size_t)tbx_ * C_R + tid];                                                           \
+        C_LDE(S, 0) C_LDE(S, 1) C_LDE(S, 2) C_LDE(S, 3) C_LDE(S, 4) C_LDE(S, 5)                             \
+        C_LDE(S, 6) C_LDE(S, 7) C_LDE(S, 8) C_LDE(S, 9) C_LDE(S, 10) C_LDE(S, 11)                           \
+    }
+#define C_DO_BLOCK(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbc_ = (TB);                                                                              \
+        __syncthreads();                                                                                    \
+        reinterpret_cast<float4*>(Xs)[tid] = px##S;                                                         \
+        C_STE(S, 0) C_STE(S, 1) C_STE(S, 2) C_STE(S, 3) C_STE(S, 4) C_STE(S, 5)                             \
+        C_STE(S, 6) C_STE(S, 7) C_STE(S, 8) C_STE(S, 9) C_STE(S, 10) C_STE(S, 11)                           \
+        Ps[tid] = pp##S;                                                                                    \
+        Pm[tid] = pm##S;                                                                                    \
+        if (tid == 0) Ps[C_R] = len##S;                                                                     \
+        const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
+        __syncthreads();                                                                                    \
+        const int tb_next = min(tbc_ + 2, tb1 - 1);                                                         \
+        if (early) C_PREFETCH(S, tb_next)                                                                   \
+        walk(cur_seg0, cur_len);                                                                            \
+        if (!early) C_PREFETCH(S, tb_next)                                                                  \
+    }
+
+    auto walk = [&](int cur_seg0, int cur_len) {
+        for (int w0 = 0; w0 < cur_len; w0 += C_ECAP) {
+            if (w0 > 0) {   // rare: segment longer than one window
+                __syncthreads();
+                for (int i = tid; i < min(C_ECAP, cur_len - w0); i += C_THREADS) Es[i] = t.ent[cur_seg0 + w0 + i];
+                __syncthreads();
+            }
+            const int w1 = w0 + C_ECAP;
+            const int k = tid;                           // sorted position: wave w walks positions 64w .. 64w + 63
+            const int s = max(Ps[k], w0), e = min(Ps[k + 1], w1);
+            if (s < e) {
+                const int rl = Pm[k];
+                int p = s - w0;
+                const int pe_ = e - w0;
+                const char* xb = reinterpret_cast<const char*>(Xs);
+                if constexpr (BWD) {
+                    BwdDst1T op;
+                    op.load(S0[rl], S1[rl], S2[rl]);
+                    for (; p + 1 < pe_; p += 2) {
+                        const int2 e0 = Es[p], e1 = Es[p + 1];
+                        const float x0 = *reinterpret_cast<const float*>(xb + e0.x);
+                        const float x1 = *reinterpret_cast<const float*>(xb + e1.x);
+                        op.edge1(x0, __int_as_float(e0.y));
+                        op.edge1(x1, __int_as_float(e1.y));
+                    }
+                    if (p < pe_) {
+                        const int2 e0 = Es[p];
+                        op.edge1(*reinterpret_cast<const float*>(xb + e0.x), __int_as_float(e0.y));
+                    }
+                    op.store(&S0[rl]);
+                } else {
+                    Fwd1T op;
+                    op.load(S0[rl], S1[rl]);
+                    for (; p + 1 < pe_; p += 2) {
+                        const int2 e0 = Es[p], e1 = Es[p + 1];
+                        const float x0 = *reinterpret_cast<const float*>(xb + e0.x);
+                        const float x1 = *reinterpret_cast<const float*>(xb + e1.x);
+                        op.edge2(x0, __int_as_float(e0.y), x1, __int_as_float(e1.y));
+                    }
+                    if (p < pe_) {
+                        const int2 e0 = Es[p];
+                        op.edge1(*reinterpret_cast<const float*>(xb + e0.x), __int_as_float(e0.y));
+                    }
+                    op.store(&S0[rl]);
+                }
+            }
+        }
+    };
+
+    float4 pxA, pxB;
+    int2 peA0, peA1, peA2, peA3, peA4, peA5, peA6, peA7, peA8, peA9, peA10, peA11;
+    int2 peB0, peB1, peB2, peB3, peB4, peB5, peB6, peB7, peB8, peB9, peB10, peB11;
+    int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
+    const bool early = wave < C_THREADS / 128;
+    if (tb0 < tb1) {
+        C_PREFETCH(A, tb0)
+        C_PREFETCH(B, min(tb0 + 1, tb1 - 1))
+    }
+    for (int tb = tb0; tb < tb1; tb += 2) {
+        C_DO_BLOCK(A, tb)
+        if (tb + 1 < tb1) C_DO_BLOCK(B, tb + 1)
+    }
+#undef C_LDE
+#undef C_STE
+#undef C_PREFETCH
+#undef C_DO_BLOCK
+    __syncthreads();
+    if (tid < n_rows) {
+        if constexpr (BWD) BwdDst1T::epilogue(a, row0 + tid, S0[tid]);
+        else Fwd1T::epilogue(a, row0 + tid, S0[tid], S1[tid]);
+    }
+}
+
+static TiledDev tiled_dev(const Tiled& tl, int n_dst, int n_src) {
+    TiledDev d;
+    d.tile_blk = tl.tile_blk; d.blk_id = tl.blk_id; d.ptr2 = tl.ptr2; d.perm = tl.perm;
+    d.ent = reinterpret_cast<const int2*>(tl.ent);
+    d.n_tiles = tl.n_tiles; d.n_dst = n_dst; d.n_src = n_src;
+    return d;
+}
+
+int launch_fwd1_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_params, const ConvWs& w,
+                      const float* x_src, const float* x_dst, float* h_out, hipStream_t s) {
+    if (tl.n_tiles == 0) return MLLP_OK;
+    Fwd1TiledArgs a;
+    a.X = x_src; a.xd = x_dst; a.derived = w.derived; a.p = conv_params_at(conv_params, 1);
+    a.h = h_out; a.Z = w.Z; a.aux = w.aux;
+    hipLaunchKernelGGL((scalar_tiled_kernel<false, Fwd1TiledArgs>), dim3((unsigned)tl.n_tiles), dim3(C_THREADS), 0, s,
+                       tiled_dev(tl, n_dst, n_src), a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "fwd1_tiled");
+}
+
+int launch_bwddst1_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w, const float* x_src, hipStream_t s) {
+    if (tl.n_tiles == 0) return MLLP_OK;
+    BwdDst1TiledArgs a{x_src, w.rec, w.dqp, w.dsdt};
+    hipLaunchKernelGGL((scalar_tiled_kernel<true, BwdDst1TiledArgs>), dim3((unsigned)tl.n_tiles), dim3(C_THREADS), 0, s,
+                       tiled_dev(tl, n_dst, n_src), a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwddst1_tiled");
+}
+
 // timing-only ablation switch (MLLP_TILED_ABLATION environment variable; 0 in production)
 static int g_tiled_ablation = [] {
     const char* e = getenv("MLLP_TILED_ABLATION");
@@ -942,8 +1237,10 @@ int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bu
         *rows_per_tile = T_R; *cols_per_block = T_CB; *bundle_capacity = T_ECAP;
     } else if (variant == 1) {   // attention forward sweep
         *rows_per_tile = F_R; *cols_per_block = F_CB; *bundle_capacity = F_ECAP;
-    } else {                     // attention backward, source-major: columns are 160-byte records
+    } else if (variant == 2) {   // attention backward, source-major: columns are 160-byte records
         *rows_per_tile = S_R; *cols_per_block = S_CB; *bundle_capacity = S_ECAP;
+    } else {                     // layer-1 (scalar) attention sweeps, destination-major
+        *rows_per_tile = C_R; *cols_per_block = C_CB; *bundle_capacity = C_ECAP;
     }
     return MLLP_OK;
 }

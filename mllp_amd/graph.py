@@ -157,8 +157,9 @@ class LPBatch:
         dest = ptr2[pos_key] + (new_off - start_idx)
         del ar, start_idx, pos_key, new_off
         ent = torch.empty((nnz, 2), dtype=torch.int32, device=dev)
-        # byte offset of the column's staged item inside the block: 64-byte feature rows, or 160-byte backward records (variant 2)
-        ent[dest, 0] = (idx - blk * CB) * (160 if variant == 2 else 64)
+        # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records
+        # (variant 2) or 4-byte scalars (variant 3)
+        ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4}[int(variant)]
         ent[dest, 1] = val.view(torch.int32)
         del dest, blk
         perm = order.reshape(-1).to(torch.int32).contiguous()
@@ -177,6 +178,11 @@ class LPBatch:
         self._tiled[(bool(transpose), int(variant))] = keep          # the library borrows these arrays
         return dict(rows_per_tile=R, cols_per_block=CB, n_tiles=n_tiles, n_tb=n_tb, max_run=max_run,
                     staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
+
+    def enable_tiled_all(self):
+        """Attach every LDS-tiled copy (variants 0-3, both orientations): the throughput configuration for batches
+        of hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""
+        return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (0, 1, 2, 3)}
 
     def disable_tiled(self, transpose=False, variant=0):
         _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), int(variant), 0, 0, 0, c_void_p(0),

@@ -508,3 +508,51 @@ def test_tiled_attention_backward_src_equals_generic_and_oracle(LPBatch, weights
     loss, logits, grads = sb.loss_step(flat_gpu)
     close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "logits with tiled forward + backward copies")
     close(grads.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "grads with tiled forward + backward copies")
+
+
+def test_tiled_layer1_sweeps_equal_generic_and_oracle(LPBatch, weights):
+    """LDS-tiled layer-1 (one channel) attention sweeps (variant 3: lane per row) vs the generic sweeps: forward
+    h / Z / aux, backward parameter gradients, both orientations, ragged last column block and tiles straddling
+    instances; then the whole model with every tiled copy attached vs the fp64 oracle."""
+    from mllp_amd.graph import synthetic_batch
+    flat, sd, flat_gpu = weights
+    sb = synthetic_batch(n_inst=4, m=600, n=1101, mean_row_nnz=30.0, seed=47, chunk=2)
+    rng = np.random.default_rng(6)
+    up16 = lambda v: (v + 15) // 16 * 16
+    for dst_is_var, off in ((False, 144), (True, 0)):
+        nd, ns = (sb.N, sb.M) if dst_is_var else (sb.M, sb.N)
+        cp = flat_gpu[off:off + 144].contiguous()
+        xs = torch.tensor(rng.standard_normal(ns).astype(np.float32), device="cuda")
+        xd = torch.tensor(rng.standard_normal(nd).astype(np.float32), device="cuda")
+        dh = torch.tensor(rng.standard_normal((nd, 16)).astype(np.float32), device="cuda")
+        ws_a, ws_b = sb.tconv_workspace(dst_is_var, 1), sb.tconv_workspace(dst_is_var, 1)
+        h_a = sb.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws_a)
+        pg_a = sb.tconv_bwd(dst_is_var, 1, cp, xs, xd, h_a, ws_a, dh)[0]
+        assert sb.enable_tiled(dst_is_var, variant=3) is not None
+        h_b = sb.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws_b)
+        close(h_b.cpu().numpy(), h_a.cpu().numpy(), 2e-6, "layer-1 h tiled vs generic")
+        o_ = up16(1088) + up16(nd) + up16(nd)                  # skip derived, q', t  (api.cpp::conv_ws_carve, cin = 1)
+        close(ws_b[o_:o_ + nd].cpu().numpy(), ws_a[o_:o_ + nd].cpu().numpy(), 2e-6, "layer-1 Z tiled vs generic")
+        o_ += up16(nd)
+        close(ws_b[o_:o_ + nd * 4].cpu().numpy(), ws_a[o_:o_ + nd * 4].cpu().numpy(), 2e-6, "layer-1 aux tiled vs generic")
+        pg_b = sb.tconv_bwd(dst_is_var, 1, cp, xs, xd, h_b, ws_b, dh)[0]
+        keep = np.ones(144, bool)
+        keep[16:32] = False                                     # lin_key.bias (cancels in the softmax)
+        close(pg_b.cpu().numpy()[keep], pg_a.cpu().numpy()[keep], 2e-5, "layer-1 param grads tiled vs generic")
+        assert torch.equal(sb.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws_b), h_b)                  # run-to-run bitwise
+    ptr, idx, val = sb.export(0), sb.export(1), sb.export(2)
+    insts = []
+    for k in range(4):
+        r0, r1 = k * 600, (k + 1) * 600
+        e0, e1 = ptr[r0], ptr[r1]
+        insts.append(LPInstance(f"s{k}", (ptr[r0:r1 + 1] - e0).astype(np.int64), (idx[e0:e1] - k * 1101).astype(np.int32),
+                                val[e0:e1].astype(np.float64), sb.x1[k * 1101:(k + 1) * 1101].cpu().numpy().astype(np.float64),
+                                sb.x2[r0:r1].cpu().numpy().astype(np.float64),
+                                sb.labels[k * 1101:(k + 1) * 1101].cpu().numpy().astype(np.int32)))
+    for tr in (False, True):
+        for v in (0, 1, 2):
+            assert sb.enable_tiled(tr, variant=v) is not None
+    r = o2.gnn_forward_backward(sd, o2.BatchCSR(insts))
+    loss, logits, grads = sb.loss_step(flat_gpu)
+    close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "logits with every tiled copy")
+    close(grads.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "grads with every tiled copy")

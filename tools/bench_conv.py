@@ -40,3 +40,19 @@ for dst_is_var, off in ((False, 1392), (True, 288)):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"dst_is_var={dst_is_var} conv bwd (all kernels) generic {ms_g:.3f} ms, with tiled source sweep {ms_t:.3f} ms  maxrel={err:.2e}  {info}")
     b.disable_tiled(not dst_is_var, variant=2); b.disable_tiled(dst_is_var, variant=1)
+# layer-1 (one channel) convs: generic sweeps vs LDS-tiled (variant 3)
+for dst_is_var, off in ((False, 144), (True, 0)):
+    nd, ns = (b.N, b.M) if dst_is_var else (b.M, b.N)
+    cp = params[off:off + 144].contiguous()
+    xs = torch.randn(ns, device="cuda"); xd = torch.randn(nd, device="cuda"); dh = torch.randn(nd, 16, device="cuda")
+    ws = b.tconv_workspace(dst_is_var, 1)
+    h = b.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws).clone()
+    ms_f = timed(lambda: b.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws))
+    ms_b = timed(lambda: b.tconv_bwd(dst_is_var, 1, cp, xs, xd, h, ws, dh))
+    info = b.enable_tiled(dst_is_var, variant=3)
+    h2 = b.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws)
+    err = (h2 - h).abs().max().item() / h.abs().max().item()
+    ms_ft = timed(lambda: b.tconv_fwd(dst_is_var, 1, cp, xs, xd, ws))
+    ms_bt = timed(lambda: b.tconv_bwd(dst_is_var, 1, cp, xs, xd, h, ws, dh))
+    print(f"dst_is_var={dst_is_var} layer-1 conv fwd generic {ms_f:.3f} ms tiled {ms_ft:.3f} ms | bwd generic {ms_b:.3f} ms tiled {ms_bt:.3f} ms  maxrel={err:.2e} {info}")
+    b.disable_tiled(dst_is_var, variant=3)

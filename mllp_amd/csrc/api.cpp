@@ -164,7 +164,7 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
 extern "C" int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block,
                                    int32_t* bundle_capacity) {
     REQUIRE(rows_per_tile && cols_per_block && bundle_capacity, "null argument");
-    REQUIRE(variant >= 0 && variant <= 3, "variant must be 0 (SpMM), 1 (attention forward), 2 (attention backward, source-major) or 3 (layer-1 sweeps)");
+    REQUIRE(variant >= 0 && variant <= 4, "variant must be 0 (SpMM), 1 (attention forward), 2 / 4 (attention backward, source- / destination-major) or 3 (layer-1 sweeps)");
     int a, b, c;
     tiled_geometry(variant, &a, &b, &c);
     *rows_per_tile = a; *cols_per_block = b; *bundle_capacity = c;
@@ -176,9 +176,10 @@ extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int varia
                                        const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
                                        const int32_t* d_perm, const int32_t* d_ent) {
     REQUIRE(g, "null graph");
-    REQUIRE(variant >= 0 && variant <= 3, "variant must be 0 (SpMM), 1 (attention forward), 2 (attention backward, source-major) or 3 (layer-1 sweeps)");
+    REQUIRE(variant >= 0 && variant <= 4, "variant must be 0 (SpMM), 1 (attention forward), 2 / 4 (attention backward, source- / destination-major) or 3 (layer-1 sweeps)");
     Orient& o = transpose ? g->At : g->A;
-    Tiled& tl = variant == 0 ? o.tiled : (variant == 1 ? o.tiled_attn : (variant == 2 ? o.tiled_bsrc : o.tiled_scalar));
+    Tiled* tls[5] = {&o.tiled, &o.tiled_attn, &o.tiled_bsrc, &o.tiled_scalar, &o.tiled_bdst};
+    Tiled& tl = *tls[variant];
     if (n_tiles == 0) {   // detach
         tl = Tiled();
         return MLLP_OK;

@@ -44,6 +44,7 @@ struct Tiled {
 struct Orient {
     Tiled tiled;        // variant 0: geometry of the plain SpMM
     Tiled tiled_attn;   // variant 1: geometry of the attention forward sweep
+    Tiled tiled_bdst;   // variant 4: geometry of the destination-major attention backward sweep
     Tiled tiled_scalar; // variant 3: geometry of the layer-1 (one channel) attention sweeps, destination-major
     Tiled tiled_bsrc;   // variant 2: geometry of the source-major attention backward sweep (this orientation = its rows)
     int n_dst = 0, n_src = 0;
@@ -137,6 +138,8 @@ int launch_fwd16_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_
 int launch_fwd1_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_params, const ConvWs& w,
                       const float* x_src, const float* x_dst, float* h_out, hipStream_t s);
 int launch_bwddst1_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w, const float* x_src, hipStream_t s);
+int launch_bwddst16_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w, const float* x_src, const float* g,
+                          float* dx_dst, int accumulate, hipStream_t s);
 int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* rec, const float* x_rows, float* dx,
                           int accumulate, hipStream_t s);
 int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bundle_capacity);

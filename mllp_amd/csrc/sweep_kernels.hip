@@ -761,6 +761,8 @@ int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, cons
     BwdDstArgs a;
     a.X = x_src; a.rec = w.rec; a.g = g; a.derived = w.derived;
     a.dqp = w.dqp; a.dsdt = w.dsdt; a.dx_dst = dx_dst; a.accumulate = accumulate;
+    if (cin == 16 && o.tiled_bdst.n_tiles > 0)
+        return launch_bwddst16_tiled(o.tiled_bdst, o.n_dst, o.n_src, w, x_src, g, dx_dst, accumulate, s);
     if (cin == 16) return launch_sweep<BwdDst16Op, 4, 4>(o, a, scratch, s, "attn_bwd_dst16");
     a.dx_dst = nullptr;
     if (o.tiled_scalar.n_tiles > 0) return launch_bwddst1_tiled(o.tiled_scalar, o.n_dst, o.n_src, w, x_src, s);

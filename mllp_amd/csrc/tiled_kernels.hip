@@ -893,6 +893,216 @@ int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* 
 }
 
 // =================================================================================================
+// Attention backward, destination-major, in the tiled form: ds_i, dt_i, dq'_i and the destination-side input
+// gradient (sweep_kernels.hip::BwdDst16Op).  A row needs its record {q', gv, t, rowmax, 1/rowsum, ge, c} AND the
+// running {dq'[16], ds, dt}: 224 bytes per row, so the tile is 256 rows (56 KB) and the column block 768 sources
+// (48 KB of H).  Geometry (variant 4): 256 rows x 768 columns, 3072-entry windows.  256 rows are one bundle per
+// wave, so every wave takes 8 quads from the long end of the length-sorted order and 8 from the short end.
+// =================================================================================================
+constexpr int D_R = 256;
+constexpr int D_CB = 768;
+constexpr int D_ECAP = 3 * T_THREADS;      // 3072 entries (24 KB) per window
+static_assert(D_CB * 4 == 3 * T_THREADS, "H block staged with 3 float4 per thread");
+
+struct BwdDstTiledArgs {
+    const float* __restrict__ X;        // [n_src, 16]
+    const float* __restrict__ rec;      // [n_dst, REC_W]
+    const float* __restrict__ g;        // [n_dst, 16] relu-masked output gradient
+    const float* __restrict__ derived;
+    float* __restrict__ dqp;            // [n_dst, 16]
+    float* __restrict__ dsdt;           // [n_dst, 2]
+    float* __restrict__ dx_dst;         // [n_dst, 16] or nullptr
+    int accumulate;
+};
+
+__global__ __launch_bounds__(T_THREADS) void bwddst16_tiled_kernel(TiledDev t, BwdDstTiledArgs a) {
+    __shared__ float4 Xs[D_CB * 4];     // 48 KB  staged column block of H
+    __shared__ int2 Es[D_ECAP];         // 24 KB  entry segment (window)
+    __shared__ float4 Rq[D_R * 4];      // 16 KB  q' of the rows
+    __shared__ float4 Rg[D_R * 4];      // 16 KB  gv of the rows
+    __shared__ float4 Dq[D_R * 4];      // 16 KB  running dq'
+    __shared__ float4 Sc[D_R];          //  4 KB  {t, rowmax, rinv, ge}
+    __shared__ float4 Sd[D_R];          //  4 KB  {c, ds, dt, -}
+    __shared__ int Ps[D_R + 16];
+    __shared__ int Pm[D_R];
+    __shared__ int Sg[T_MAXB + 1];
+    __shared__ int Bk[T_MAXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = lane >> 2, part = lane & 3;
+    const int tile = xcd_tile(blockIdx.x, t.n_tiles);
+    const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
+    const int row0 = tile * D_R;
+    const int n_rows = min(D_R, t.n_dst - row0);
+
+    {   // per-row inputs: 4 threads per row
+        const int r = tid >> 2;
+        const bool ok = r < n_rows;
+        const float* rp = a.rec + (size_t)(row0 + (ok ? r : 0)) * REC_W;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        Rq[tid] = ok ? ld4(rp + 4 * part) : z4;
+        Rg[tid] = ok ? ld4(rp + 16 + 4 * part) : z4;
+        Dq[tid] = z4;
+        if (part == 0) {
+            Sc[r] = ok ? ld4(rp + 32) : z4;
+            Sd[r] = make_float4(ok ? rp[36] : 0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (tid <= tb1 - tb0) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * D_R];
+    if (tid < tb1 - tb0) Bk[tid] = t.blk_id[tb0 + tid];
+    __syncthreads();
+
+#define D_PREFETCH(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbx_ = (TB);                                                                              \
+        const int c0_ = Bk[tbx_ - tb0] * D_CB;                                                              \
+        const int c4_ = min(D_CB, t.n_src - c0_) * 4;                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(a.X + (size_t)c0_ * 16);                      \
+        px##S##0 = src_[min(tid, c4_ - 1)];                                                                 \
+        px##S##1 = src_[min(tid + T_THREADS, c4_ - 1)];                                                     \
+        px##S##2 = src_[min(tid + 2 * T_THREADS, c4_ - 1)];                                                 \
+        seg0##S = Sg[tbx_ - tb0];                                                                           \
+        len##S = Sg[tbx_ - tb0 + 1] - seg0##S;                                                              \
+        pp##S = t.ptr2[(size_t)tbx_ * D_R + min(tid, D_R - 1)] - seg0##S;                                   \
+        pm##S = t.perm[(size_t)tbx_ * D_R + min(tid, D_R - 1)];                                             \
+        pe##S##0 = t.ent[seg0##S + min(tid, max(len##S - 1, 0))];                                           \
+        pe##S##1 = t.ent[seg0##S + min(tid + T_THREADS, max(len##S - 1, 0))];                               \
+        pe##S##2 = t.ent[seg0##S + min(tid + 2 * T_THREADS, max(len##S - 1, 0))];                           \
+    }
+#define D_DO_BLOCK(S, TB)                                                                                   \
+    {                                                                                                       \
+        const int tbc_ = (TB);                                                                              \
+        __syncthreads();                                                                                    \
+        Xs[tid] = px##S##0; Xs[tid + T_THREADS] = px##S##1; Xs[tid + 2 * T_THREADS] = px##S##2;             \
+        Es[tid] = pe##S##0; Es[tid + T_THREADS] = pe##S##1; Es[tid + 2 * T_THREADS] = pe##S##2;             \
+        if (tid < D_R) {                                                                                    \
+            Ps[tid] = pp##S;                                                                                \
+            Pm[tid] = pm##S;                                                                                \
+        }                                                                                                   \
+        if (tid == 0) Ps[D_R] = len##S;                                                                     \
+        const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
+        __syncthreads();                                                                                    \
+        const int tb_next = min(tbc_ + 2, tb1 - 1);                                                         \
+        if (early) D_PREFETCH(S, tb_next)                                                                   \
+        walk(cur_seg0, cur_len);                                                                            \
+        if (!early) D_PREFETCH(S, tb_next)                                                                  \
+    }
+
+    // sorted position of this quad: 8 quads of a wave from the long end, 8 from the short end
+    const int kq = quad < 8 ? wave * 8 + quad : D_R - 1 - (wave * 8 + (quad - 8));
+    auto walk = [&](int cur_seg0, int cur_len) {
+        for (int w0 = 0; w0 < cur_len; w0 += D_ECAP) {
+            if (w0 > 0) {   // rare: segment longer than one window
+                __syncthreads();
+                for (int i = tid; i < min(D_ECAP, cur_len - w0); i += T_THREADS) Es[i] = t.ent[cur_seg0 + w0 + i];
+                __syncthreads();
+            }
+            const int w1 = w0 + D_ECAP;
+            const int s = max(Ps[kq], w0), e = min(Ps[kq + 1], w1);
+            if (s < e) {
+                const int rl = Pm[kq];
+                const float4 qp = Rq[rl * 4 + part], gv = Rg[rl * 4 + part], sc = Sc[rl];   // sc = {t, rowmax, rinv, ge}
+                float4 dq = Dq[rl * 4 + part], sd = Sd[rl];                                 // sd = {c, ds, dt, -}
+                int p = s - w0;
+                const int pe_ = e - w0;
+                for (; p + 1 < pe_; p += 2) {
+                    const int2 e0 = Es[p], e1 = Es[p + 1];
+                    const float4 x0 = Xs[(e0.x >> 4) + part], x1 = Xs[(e1.x >> 4) + part];
+                    const float a0 = __int_as_float(e0.y), a1 = __int_as_float(e1.y);
+                    const float l0 = fmaf(a0, sc.x, quad_sum4(dot4(qp, x0)));
+                    const float l1 = fmaf(a1, sc.x, quad_sum4(dot4(qp, x1)));
+                    const float al0 = exp_acc_t(l0 - sc.y) * sc.z, al1 = exp_acc_t(l1 - sc.y) * sc.z;
+                    const float dl0 = al0 * (quad_sum4(dot4(gv, x0)) + fmaf(a0, sc.w, sd.x));
+                    const float dl1 = al1 * (quad_sum4(dot4(gv, x1)) + fmaf(a1, sc.w, sd.x));
+                    sd.y += dl0;
+                    sd.z = fmaf(dl0, a0, sd.z);
+                    fma4(dl0, x0, dq);
+                    sd.y += dl1;
+                    sd.z = fmaf(dl1, a1, sd.z);
+                    fma4(dl1, x1, dq);
+                }
+                if (p < pe_) {
+                    const int2 e0 = Es[p];
+                    const float4 x0 = Xs[(e0.x >> 4) + part];
+                    const float a0 = __int_as_float(e0.y);
+                    const float l0 = fmaf(a0, sc.x, quad_sum4(dot4(qp, x0)));
+                    const float al0 = exp_acc_t(l0 - sc.y) * sc.z;
+                    const float dl0 = al0 * (quad_sum4(dot4(gv, x0)) + fmaf(a0, sc.w, sd.x));
+                    sd.y += dl0;
+                    sd.z = fmaf(dl0, a0, sd.z);
+                    fma4(dl0, x0, dq);
+                }
+                Dq[rl * 4 + part] = dq;
+                if (part == 0) Sd[rl] = sd;
+            }
+        }
+    };
+
+    float4 pxA0, pxA1, pxA2, pxB0, pxB1, pxB2;
+    int2 peA0, peA1, peA2, peB0, peB1, peB2;
+    int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
+    const bool early = wave < T_WAVES / 2;
+    if (tb0 < tb1) {
+        D_PREFETCH(A, tb0)
+        D_PREFETCH(B, min(tb0 + 1, tb1 - 1))
+    }
+    for (int tb = tb0; tb < tb1; tb += 2) {
+        D_DO_BLOCK(A, tb)
+        if (tb + 1 < tb1) D_DO_BLOCK(B, tb + 1)
+    }
+#undef D_PREFETCH
+#undef D_DO_BLOCK
+    __syncthreads();
+
+    // ---- epilogue: 16 lanes per row (lane gl = input channel), 64 rows per pass ----
+    //      dx_i = Ws^T g_i + Pq^T dq'_i + ds_i Pb + dt_i Pt          (sweep_kernels.hip::BwdDst16Op::epilogue)
+    const int gl = tid & 15;
+    const float* D = a.derived;
+    float wsT[16], pqT[16];
+    float pb = 0.f, pt = 0.f;
+    if (a.dx_dst) {
+        load_row16(D + OFF_WST + gl * 16, wsT);
+        load_row16(D + OFF_PQT + gl * 16, pqT);
+        pb = D[OFF_PB + gl];
+        pt = D[OFF_PT + gl];
+    }
+    for (int r = tid >> 4; r < n_rows; r += T_THREADS / 16) {
+        const size_t row = (size_t)row0 + r;
+        const float4 sd = Sd[r];
+        float da[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = Dq[r * 4 + q];
+            da[4 * q] = v.x; da[4 * q + 1] = v.y; da[4 * q + 2] = v.z; da[4 * q + 3] = v.w;
+        }
+        a.dqp[row * 16 + gl] = select16(da, gl);
+        if (gl == 0) reinterpret_cast<float2*>(a.dsdt)[row] = make_float2(sd.y, sd.z);
+        if (a.dx_dst) {
+            float gr[16];
+            load_row16(a.g + row * 16, gr);
+            float v = dot16(wsT, gr, 0.0f);
+            v = fmaf(sd.y, pb, v);
+            v = fmaf(sd.z, pt, v);
+            v = dot16(pqT, da, v);
+            float* dst = a.dx_dst + row * 16 + gl;
+            *dst = a.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+int launch_bwddst16_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w, const float* x_src, const float* g,
+                          float* dx_dst, int accumulate, hipStream_t s) {
+    if (tl.n_tiles == 0) return MLLP_OK;
+    TiledDev d;
+    d.tile_blk = tl.tile_blk; d.blk_id = tl.blk_id; d.ptr2 = tl.ptr2; d.perm = tl.perm;
+    d.ent = reinterpret_cast<const int2*>(tl.ent);
+    d.n_tiles = tl.n_tiles; d.n_dst = n_dst; d.n_src = n_src;
+    BwdDstTiledArgs a{x_src, w.rec, g, w.derived, w.dqp, w.dsdt, dx_dst, accumulate};
+    hipLaunchKernelGGL(bwddst16_tiled_kernel, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwddst16_tiled");
+}
+
+// =================================================================================================
 // Layer-1 attention sweeps (scalar node features, reference linear_program_methods.py:90-91, 241-242) in the
 // tiled form.  The generic sweeps gather one 4-byte x_j per nonzero and lane from L2 (one request per nonzero:
 // 4.4 ms forward, 3.1 ms backward at 512 M nonzeros).  With one channel a column block of 1024 sources is only
@@ -1239,8 +1449,10 @@ int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bu
         *rows_per_tile = F_R; *cols_per_block = F_CB; *bundle_capacity = F_ECAP;
     } else if (variant == 2) {   // attention backward, source-major: columns are 160-byte records
         *rows_per_tile = S_R; *cols_per_block = S_CB; *bundle_capacity = S_ECAP;
-    } else {                     // layer-1 (scalar) attention sweeps, destination-major
+    } else if (variant == 3) {   // layer-1 (scalar) attention sweeps, destination-major
         *rows_per_tile = C_R; *cols_per_block = C_CB; *bundle_capacity = C_ECAP;
+    } else {                     // attention backward, destination-major
+        *rows_per_tile = D_R; *cols_per_block = D_CB; *bundle_capacity = D_ECAP;
     }
     return MLLP_OK;
 }

@@ -159,7 +159,7 @@ class LPBatch:
         ent = torch.empty((nnz, 2), dtype=torch.int32, device=dev)
         # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records
         # (variant 2) or 4-byte scalars (variant 3)
-        ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4}[int(variant)]
+        ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4, 4: 64}[int(variant)]
         ent[dest, 1] = val.view(torch.int32)
         del dest, blk
         perm = order.reshape(-1).to(torch.int32).contiguous()
@@ -180,7 +180,8 @@ class LPBatch:
                     staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
 
     def enable_tiled_all(self):
-        """Attach every LDS-tiled copy (variants 0-3, both orientations): the throughput configuration for batches
+        """Attach every LDS-tiled copy (variants 0-3, both orientations; variant 4, the destination-major backward
+        sweep, measured no faster than the generic one and is left out): the throughput configuration for batches
         of hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""
         return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (0, 1, 2, 3)}
 

@@ -494,6 +494,15 @@ def test_tiled_attention_backward_src_equals_generic_and_oracle(LPBatch, weights
         close(dxd_b.cpu().numpy(), dxd_a.cpu().numpy(), 1e-7, "dx_dst unchanged")
         close(pg_b.cpu().numpy(), pg_a.cpu().numpy(), 1e-7, "param grads unchanged")
         assert torch.equal(sb.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)[2], dxs_b)      # run-to-run bitwise
+        # destination-major backward sweep on its own tiled copy (variant 4, the conv's own orientation)
+        assert sb.enable_tiled(dst_is_var, variant=4) is not None
+        pg_c, dxd_c, dxs_c, _ = sb.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)
+        close(dxd_c.cpu().numpy(), dxd_a.cpu().numpy(), 2e-6, "dx_dst tiled vs generic")
+        keep = np.ones(1104, bool)
+        keep[256:272] = False                                   # lin_key.bias
+        close(pg_c.cpu().numpy()[keep], pg_a.cpu().numpy()[keep], 2e-5, "param grads, tiled destination sweep")
+        assert torch.equal(dxs_c, dxs_b)
+        assert torch.equal(sb.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)[1], dxd_c)      # run-to-run bitwise
     ptr, idx, val = sb.export(0), sb.export(1), sb.export(2)
     insts = []
     for k in range(4):

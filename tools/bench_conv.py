@@ -39,7 +39,10 @@ for dst_is_var, off in ((False, 1392), (True, 288)):
     ms_t = timed(lambda: b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)); got = b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh)[2]
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"dst_is_var={dst_is_var} conv bwd (all kernels) generic {ms_g:.3f} ms, with tiled source sweep {ms_t:.3f} ms  maxrel={err:.2e}  {info}")
-    b.disable_tiled(not dst_is_var, variant=2); b.disable_tiled(dst_is_var, variant=1)
+    info = b.enable_tiled(dst_is_var, variant=4)
+    ms_d = timed(lambda: b.tconv_bwd(dst_is_var, 16, cp, xs, xd, h, ws, dh))
+    print(f"dst_is_var={dst_is_var} conv bwd with tiled source AND destination sweeps {ms_d:.3f} ms  {info}")
+    b.disable_tiled(not dst_is_var, variant=2); b.disable_tiled(dst_is_var, variant=1); b.disable_tiled(dst_is_var, variant=4)
 # layer-1 (one channel) convs: generic sweeps vs LDS-tiled (variant 3)
 for dst_is_var, off in ((False, 144), (True, 0)):
     nd, ns = (b.N, b.M) if dst_is_var else (b.M, b.N)

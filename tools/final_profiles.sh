@@ -6,4 +6,6 @@ step bench_plain 900 python3 bench.py
 step bench_prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_bench -- python3 bench.py --no-cpu-baseline
 step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_fetch -- python3 tools/bench_spmm.py 256 3
 step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pmc_write -- python3 tools/bench_spmm.py 256 3
+step pmc_sq 600 bash tools/pmc_ws.sh 64
+step phase 300 python3 tools/phase_cycles.py 64
 export MLLP_BENCH_FORCE_DIST=1; step bench_dist1 600 python3 bench.py --steps 20 --no-synthetic --no-cpu-baseline

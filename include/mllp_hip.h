@@ -107,11 +107,17 @@ int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, fl
  *   d_ptr2     [n_tb * rows_per_tile + 1]  entry offsets: inside a (tile, block) the rows are ordered by their
  *                           number of entries in that block, descending (position k = k-th longest)
  *   d_perm     [n_tb * rows_per_tile]      row (inside its tile) of every sorted position
- *   d_ent      [nnz][2]     {column id inside its block, fp32 value bits}, ordered by (tile, block, position, column)
+ *   d_ent      [nnz][2]     {byte offset of the column's staged item inside its block (64 * local column for
+ *                           variants 0, 1, 4), fp32 value bits}, ordered by (tile, block, position); inside a row
+ *                           round-robin over (local column mod 4) (LDS bank spreading)
  * The arrays are BORROWED: the caller keeps them alive while attached (n_tiles = 0 detaches).
- * variant 0 is the geometry of the plain SpMM (mllp_spmm_csr_f32 uses it when attached), variant 1 the
- * geometry of the attention sweeps (the forward sweep of mllp_tconv_fwd / mllp_gnn_* uses it when attached:
- * it keeps the per-row query and softmax state in LDS, hence smaller column blocks).                */
+ * variant 0 is the geometry of the plain SpMM (mllp_spmm_csr_f32 uses it when attached); variant 1 the attention
+ * forward sweep with 16 channels (per-row query and softmax state in LDS, hence smaller column blocks); variant 2
+ * the source-major attention backward sweep (attach it to the orientation whose ROWS are the conv's source nodes;
+ * the staged items are the 160-byte backward records, d_ent[.][0] = 160 * local column); variant 3 the layer-1
+ * (one channel) forward and destination-major backward sweeps (staged items are scalars, d_ent[.][0] = 4 * local
+ * column); variant 4 the destination-major attention backward sweep.  mllp_tconv_* / mllp_gnn_* use whichever
+ * copies are attached and fall back to the generic sweeps (HIP as well) otherwise.                    */
 int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity);
 int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int variant, int64_t n_tiles, int64_t n_tb,
                             int32_t max_blocks_per_tile /* largest tile_blk[t+1]-tile_blk[t]; at most 255 */,

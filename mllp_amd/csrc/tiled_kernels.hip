@@ -284,6 +284,13 @@ void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __rest
     const int tile = xcd_tile(blockIdx.x, t.n_tiles);
     const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
     const int nb = tb1 - tb0;
+    if (nb == 0) {      // a tile whose rows are all empty: nothing to stage (the loaders' lookahead needs >= 1 block)
+        const int n4z = min(T_R, t.n_dst - tile * T_R) * 4;
+        float4* dz = reinterpret_cast<float4*>(Y + (size_t)tile * T_R * 16);
+        if (!(ABL & 16))
+            for (int i = tid; i < n4z; i += T_THREADS) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
 
     for (int i = tid; i < T_R * 4; i += T_THREADS) Ya[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid <= nb) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * T_R];

@@ -156,7 +156,8 @@ class LPBatch:
         del ordr
         dest = ptr2[pos_key] + (new_off - start_idx)
         del ar, start_idx, pos_key, new_off
-        ent = torch.empty((nnz, 2), dtype=torch.int32, device=dev)
+        # one padding entry behind the last: an empty (tile, block) at the very end still has a readable "first entry"
+        ent = torch.zeros((nnz + 1, 2), dtype=torch.int32, device=dev)
         # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records
         # (variant 2) or 4-byte scalars (variant 3)
         ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4, 4: 64}[int(variant)]

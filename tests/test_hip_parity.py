@@ -565,3 +565,57 @@ def test_tiled_layer1_sweeps_equal_generic_and_oracle(LPBatch, weights):
     loss, logits, grads = sb.loss_step(flat_gpu)
     close(logits.cpu().numpy(), r["logits"], RTOL_ACT, "logits with every tiled copy")
     close(grads.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "grads with every tiled copy")
+
+
+def _holes_instance(seed, m, n):
+    """Random LP with empty rows, empty columns and a few dense rows (ragged input for the tiled copies)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for i in range(m):
+        u = rng.random()
+        k = 0 if u < 0.3 else (int(rng.integers(1, 4)) if u < 0.6 else (n // 2 if u > 0.98 else int(rng.poisson(12)) + 1))
+        cols = np.sort(rng.choice(n - n // 10, size=min(k, n - n // 10), replace=False)).astype(np.int32)   # last 10 % of the columns stay empty
+        rows.append(cols)
+    indptr = np.zeros(m + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+    values = rng.standard_normal(indptr[-1])
+    return LPInstance(f"holes{seed}", indptr, indices, values, rng.standard_normal(n), rng.random(m) * 5,
+                      (rng.random(n) < 0.37).astype(np.int32))
+
+
+def test_tiled_copies_edge_cases(LPBatch, weights):
+    """Every tiled variant on ragged inputs: empty rows / columns / whole column blocks, dense rows, a 3 x 5 instance,
+    tiles straddling instances, and segments longer than the LDS window (several windows per block, odd and even
+    item counts).  Whole-model loss step and plain SpMM with all copies attached == generic sweeps == fp64 oracle."""
+    from mllp_amd.graph import synthetic_batch
+    flat, sd, flat_gpu = weights
+    insts = [_holes_instance(1, 700, 900), _holes_instance(2, 3, 5), _holes_instance(3, 515, 2300)]
+    b = LPBatch.from_instances(insts)
+    H = torch.randn(b.N, 16, device="cuda")
+    Ht = torch.randn(b.M, 16, device="cuda")
+    y_ref, yt_ref = b.spmm(H).clone(), b.spmm(Ht, transpose=True).clone()
+    loss_a, logits_a, grads_a = [t.clone() for t in b.loss_step(flat_gpu)]
+    for tr in (False, True):
+        for v in (0, 1, 2, 3, 4):
+            assert b.enable_tiled(tr, variant=v) is not None
+    close(b.spmm(H).cpu().numpy(), y_ref.cpu().numpy(), 2e-6, "A H with holes")
+    close(b.spmm(Ht, transpose=True).cpu().numpy(), yt_ref.cpu().numpy(), 2e-6, "At H with holes")
+    loss_b, logits_b, grads_b = b.loss_step(flat_gpu)
+    close(logits_b.cpu().numpy(), logits_a.cpu().numpy(), 5e-6, "logits, tiled vs generic, ragged batch")
+    close(grads_b.cpu().numpy()[grad_mask()], grads_a.cpu().numpy()[grad_mask()], 5e-5, "grads, tiled vs generic, ragged batch")
+    r = o2.gnn_forward_backward(sd, o2.BatchCSR(insts))
+    close(logits_b.cpu().numpy(), r["logits"], RTOL_ACT, "logits, tiled, ragged batch vs oracle")
+    close(grads_b.cpu().numpy()[grad_mask()], r["grads"][grad_mask()], RTOL_GRAD, "grads, tiled, ragged batch vs oracle")
+    # multi-window segments in every variant (40 nonzeros per row on 1000 columns)
+    d = synthetic_batch(n_inst=1, m=1024, n=1000, mean_row_nnz=40.0, seed=3, chunk=1)
+    la, lga, ga = [t.clone() for t in d.loss_step(flat_gpu)]
+    for tr in (False, True):
+        for v in (0, 1, 2, 3, 4):
+            info = d.enable_tiled(tr, variant=v)
+            assert info is not None
+            if not tr:
+                assert info["max_run"] > 3072, (v, info)
+    lb, lgb, gb = d.loss_step(flat_gpu)
+    close(lgb.cpu().numpy(), lga.cpu().numpy(), 5e-6, "logits, multi-window segments")
+    close(gb.cpu().numpy()[grad_mask()], ga.cpu().numpy()[grad_mask()], 5e-5, "grads, multi-window segments")

@@ -127,25 +127,98 @@ static int model_forward_body(const mllp_graph* g, const float* P, const float* 
     return conv_forward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, s);
 }
 
+// One conv of the backward pass, cut at its dependency points so that the two streams can interleave convs:
+//   pre   bwd_pre                        needs dh (complete), writes rec, masks dh in place
+//   dst   destination-major sweep        needs pre; writes dq', ds, dt and dx_dst
+//   src   source-major sweep             needs pre; writes dx_src                       (independent of dst)
+//   stat  parameter statistics           needs dst
+//   fin   single-workgroup finalize      needs stat
+struct ConvBwd {
+    const mllp_graph* g;
+    bool dst_is_var;
+    int cin;
+    const float* cp;
+    const ConvWs& w;
+    const float *x_src, *x_dst, *h_out;
+    float *dh, *dx_dst, *dx_src;
+    int acc;
+    float* param_grads;
+    const Orient& o() const { return dst_is_var ? g->At : g->A; }
+    const Orient& ot() const { return dst_is_var ? g->A : g->At; }
+    int pre(hipStream_t s) const { return launch_bwd_pre(o().n_dst, cin, cp, w, x_dst, h_out, dh, s); }
+    int dst(hipStream_t s) const {
+        return launch_attn_bwd_dst(o(), cin, cp, w, x_src, dh, cin == 16 ? dx_dst : nullptr, acc & 1, o().scratch, s);
+    }
+    int src(hipStream_t s) const {
+        if (cin != 16 || !dx_src) return MLLP_OK;
+        return launch_attn_bwd_src(ot(), w, x_src, dx_src, (acc >> 1) & 1, ot().scratch, s);
+    }
+    int stat(hipStream_t s) const { return launch_param_stats(cin, o().n_dst, w, x_dst, dh, s); }
+    int fin(hipStream_t s) const {
+        return launch_finalize_conv(cin, cp, w.stats, stat_blocks_for(o().n_dst), param_grads, s);
+    }
+};
+
+// Backward of the five convs on two streams (s = caller's stream, a = the graph's aux stream, already forked from s
+// by the caller).  Dependencies (linear_program_methods.py:241-247 read backwards):
+//   C3 (dst = variables)   dh = d3v;  dst -> d2v,  src -> d2c
+//   C2V (dst = variables)  dh = d2v;  dst -> d1v,  src -> d1c        (overwrite)
+//   C2C (dst = constraints) dh = d2c; dst -> d1c +=, src -> d1v +=   (after C2V's src / dst respectively: C2V runs its
+//                          source-major sweep first so that C2C's destination-major sweep can start early)
+//   C1V dh = d1v, C1C dh = d1c (inputs are data: no input gradients)
+// On the Netlib batch no single sweep fills the GPU (2.5 waves per SIMD resident), so running the source-major sweep
+// of a conv next to its destination-major one, and C2C next to C2V, shortens the step; every sweep of one
+// orientation still runs alone on that orientation's scratch (the waits below guarantee it).
 static int model_backward_body(const mllp_graph* g, const float* P, const float* x1, const float* x2,
                                const ModelWs& w, float* grads, hipStream_t s) {
     int rc;
-    hipStream_t a = g->aux;     // already forked from s by the caller (head_finalize runs there)
-    // the single-workgroup finalize kernels go to the aux stream, off the critical path
-    if ((rc = conv_backward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, w.d3v, w.d2v, w.d2c, 0,
-                            grads + OFF_C3V, s, a, g->ev[4]))) return rc;
-    if ((rc = conv_backward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, w.d2v, w.d1v, w.d1c, 0,
-                            grads + OFF_C2V, s, a, g->ev[5]))) return rc;
-    if ((rc = conv_backward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, w.d2c, w.d1c, w.d1v, 3,
-                            grads + OFF_C2C, s, a, g->ev[6]))) return rc;
+    hipStream_t a = g->aux;
+    const ConvBwd c3{g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, w.d3v, w.d2v, w.d2c, 0, grads + OFF_C3V};
+    const ConvBwd c2v{g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, w.d2v, w.d1v, w.d1c, 0, grads + OFF_C2V};
+    const ConvBwd c2c{g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, w.d2c, w.d1c, w.d1v, 3, grads + OFF_C2C};
+    const ConvBwd c1v{g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, w.d1v, nullptr, nullptr, 0, grads + OFF_C1V};
+    const ConvBwd c1c{g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, w.d1c, nullptr, nullptr, 0, grads + OFF_C1C};
+#define TRY(x) if ((rc = (x))) return rc
+#define REC(e, st) TRY(hipEventRecord(g->ev[e], st) == hipSuccess ? MLLP_OK : fail(MLLP_EHIP, "event record"))
+#define WAIT(st, e) TRY(hipStreamWaitEvent(st, g->ev[e], 0) == hipSuccess ? MLLP_OK : fail(MLLP_EHIP, "stream wait"))
+    // stream s                                     stream a
+    TRY(c3.pre(s));
+    TRY(fork_to(s, a, g->ev[8]));                // rec of C3 ready
+    TRY(c3.dst(s));  REC(9, s);                  // s: d2v
+    TRY(c3.src(a));  REC(13, a);                 //                                          a: d2c
+    TRY(c2v.pre(s));
+    WAIT(s, 13);                                 // C3's src shares A's scratch with C2V's src
+    TRY(c2v.src(s)); REC(11, s);                 // s: d1c (overwrite) first: C2C's dst waits for it
+    TRY(c2v.dst(s)); REC(10, s);                 // s: d1v (overwrite)
+    TRY(c2v.stat(s));
+    TRY(c2c.pre(a));                             //                                          a: dh = d2c
+    WAIT(a, 9);
+    TRY(c3.stat(a));                             //                                          a: needs C3's dst
+    WAIT(a, 11);
+    TRY(c2c.dst(a)); REC(14, a);                 //                                          a: d1c +=
+    WAIT(a, 10);
+    TRY(c2c.src(a)); REC(12, a);                 //                                          a: d1v +=
+    WAIT(s, 14);
+    TRY(c2c.stat(s));                            // s: statistics of C2C (its dst ran on a)
     // layer 1: the two convs are independent (their inputs are data): one per stream
-    if ((rc = fork_to(s, a, g->ev[7]))) return rc;       // aux needs d1c (complete on s)
-    if ((rc = conv_backward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, w.d1v, nullptr, nullptr, 0,
-                            grads + OFF_C1V, s))) return rc;
-    if ((rc = conv_backward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, w.d1c, nullptr, nullptr, 0,
-                            grads + OFF_C1C, a))) return rc;
-    if ((rc = launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, a))) return rc;
-    return fork_to(a, s, g->ev[0]);                      // join everything queued on aux
+    WAIT(s, 12);
+    TRY(c1v.pre(s));                             // s: dh = d1v (C2V dst + C2C src)
+    TRY(c1v.dst(s));
+    TRY(c1v.stat(s));
+    TRY(c1c.pre(a));                             //                                          a: dh = d1c (C2V src + C2C dst)
+    TRY(c1c.dst(a));
+    TRY(c1c.stat(a));
+    // single-workgroup finalize kernels last: nothing waits for them but the final join
+    TRY(c2v.fin(s));
+    TRY(c2c.fin(s));
+    TRY(c1v.fin(s));
+    TRY(c3.fin(a));
+    TRY(c1c.fin(a));
+    TRY(launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, a));
+#undef REC
+#undef WAIT
+#undef TRY
+    return fork_to(a, s, g->ev[0]);          // join everything queued on aux
 }
 
 }  // namespace mllp

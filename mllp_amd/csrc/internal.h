@@ -77,7 +77,7 @@ struct mllp_graph {
     // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
     // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
     hipStream_t aux = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[16] = {};
     std::vector<void*> allocs;   // everything to hipFree on destroy
 };
 

@@ -100,7 +100,11 @@ class LPTrainer:
     """HIP fast path: one `mllp_gnn_loss_step` + all-reduce + `mllp_adam_step` per batch, optionally
     captured in hipGraphs (the Netlib batch is launch bound: ~30 small kernels per step)."""
 
-    GRAPH_NNZ_LIMIT = 1 << 18   # "auto": capture batches up to this many nonzeros (launch-bound), run larger ones eagerly
+    # "auto": capture batches up to this many nonzeros.  0 = never: since the backward pass interleaves its convs on two
+    # streams, replaying the captured step is slower than launching it (single instances: 374-613 us vs 271-275 us eager;
+    # full Netlib batch 1.82 vs 0.94 ms; tools/graph_vs_eager.py) -- the runtime serialises the graph's branches.
+    # `use_hip_graph=True` still forces capture.
+    GRAPH_NNZ_LIMIT = 0
 
     def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph="auto",
                  global_instances: Optional[int] = None, with_metrics=False):
@@ -117,9 +121,6 @@ class LPTrainer:
         p = self._plans.get(key)
         if p is None:
             dev = self.params.device
-            # hipGraph replay removes ~40 host launches per step, which is what bounds tiny batches (one small
-            # instance per step); on the full Netlib batch the step is ~1 ms of GPU work and eager launches on two
-            # streams measured faster (0.99 ms) than replaying the captured graph (1.08 ms)
             graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),

@@ -31,10 +31,10 @@ ConvWs conv_ws_carve(float* base, int64_t n, int cin) {
 }
 
 static int conv_forward(const mllp_graph* g, bool dst_is_var, int cin, const float* cp, const ConvWs& w,
-                        const float* x_src, const float* x_dst, float* h_out, hipStream_t s) {
+                        const float* x_src, const float* x_dst, float* h_out, hipStream_t s, bool prep = true) {
     const Orient& o = dst_is_var ? g->At : g->A;
     int rc;
-    if ((rc = launch_param_prep(cp, cin, w.derived, s))) return rc;
+    if (prep && (rc = launch_param_prep(cp, cin, w.derived, s))) return rc;
     if (cin == 16 && (rc = launch_node_qp(x_dst, o.n_dst, w.derived, w.qp, w.t, s))) return rc;
     return launch_attn_fwd(o, cin, cp, w, x_src, x_dst, h_out, o.scratch, s);
 }
@@ -112,19 +112,25 @@ static int model_forward_body(const mllp_graph* g, const float* P, const float* 
                               hipStream_t s) {
     int rc;
     hipStream_t a = g->aux;
+    {   // folded weights of all five convs in one launch (they only depend on the parameters)
+        const float* cps[MODEL_CONVS] = {P + OFF_C1V, P + OFF_C1C, P + OFF_C2V, P + OFF_C2C, P + OFF_C3V};
+        const int cins[MODEL_CONVS] = {1, 1, 16, 16, 16};
+        float* ders[MODEL_CONVS] = {w.c1v.derived, w.c1c.derived, w.c2v.derived, w.c2c.derived, w.c3v.derived};
+        if ((rc = launch_param_prep_batch(MODEL_CONVS, cps, cins, ders, s))) return rc;
+    }
     // linear_program_methods.py:241-242  layer 1 (scalar inputs), both directions from the SAME inputs:
     // the w2s conv walks A^T, the s2w conv walks A -- independent, so they run on two streams
     if ((rc = fork_to(s, a, g->ev[0]))) return rc;
-    if ((rc = conv_forward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, s))) return rc;
-    if ((rc = conv_forward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, a))) return rc;
+    if ((rc = conv_forward(g, true, 1, P + OFF_C1V, w.c1v, x2, x1, w.h1v, s, false))) return rc;
+    if ((rc = conv_forward(g, false, 1, P + OFF_C1C, w.c1c, x1, x2, w.h1c, a, false))) return rc;
     if ((rc = fork_to(a, s, g->ev[1]))) return rc;       // join: layer 2 on s needs h1c
     if ((rc = fork_to(s, a, g->ev[2]))) return rc;       // ... and layer 2 on aux needs h1v
     // :244-245  layer 2 (simultaneous update: both read layer-1 outputs)
-    if ((rc = conv_forward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, s))) return rc;
-    if ((rc = conv_forward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, a))) return rc;
+    if ((rc = conv_forward(g, true, 16, P + OFF_C2V, w.c2v, w.h1c, w.h1v, w.h2v, s, false))) return rc;
+    if ((rc = conv_forward(g, false, 16, P + OFF_C2C, w.c2c, w.h1v, w.h1c, w.h2c, a, false))) return rc;
     if ((rc = fork_to(a, s, g->ev[3]))) return rc;       // join
     // :247  layer 3, variables only (gconv3_s2w is never called, :248)
-    return conv_forward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, s);
+    return conv_forward(g, true, 16, P + OFF_C3V, w.c3v, w.h2c, w.h2v, w.h3v, s, false);
 }
 
 // One conv of the backward pass, cut at its dependency points so that the two streams can interleave convs:
@@ -208,17 +214,21 @@ static int model_backward_body(const mllp_graph* g, const float* P, const float*
     TRY(c1c.pre(a));                             //                                          a: dh = d1c (C2V src + C2C dst)
     TRY(c1c.dst(a));
     TRY(c1c.stat(a));
-    // single-workgroup finalize kernels last: nothing waits for them but the final join
-    TRY(c2v.fin(s));
-    TRY(c2c.fin(s));
-    TRY(c1v.fin(s));
-    TRY(c3.fin(a));
-    TRY(c1c.fin(a));
-    TRY(launch_fill_zero(grads + OFF_C3C, OFF_FC - OFF_C3C, a));
 #undef REC
 #undef WAIT
+    TRY(fork_to(a, s, g->ev[0]));            // join everything queued on aux
 #undef TRY
-    return fork_to(a, s, g->ev[0]);          // join everything queued on aux
+    // the five single-workgroup finalize kernels (and the zero gradient of the never-used gconv3_s2w) as ONE launch
+    const ConvBwd* cs[MODEL_CONVS] = {&c1v, &c1c, &c2v, &c2c, &c3};
+    const float* cps[MODEL_CONVS];
+    const float* sts[MODEL_CONVS];
+    float* grs[MODEL_CONVS];
+    int cins[MODEL_CONVS], nbs[MODEL_CONVS];
+    for (int i = 0; i < MODEL_CONVS; ++i) {
+        cps[i] = cs[i]->cp; cins[i] = cs[i]->cin; sts[i] = cs[i]->w.stats;
+        nbs[i] = stat_blocks_for(cs[i]->o().n_dst); grs[i] = cs[i]->param_grads;
+    }
+    return launch_finalize_batch(MODEL_CONVS, cps, cins, sts, nbs, grs, grads + OFF_C3C, OFF_FC - OFF_C3C, s);
 }
 
 }  // namespace mllp

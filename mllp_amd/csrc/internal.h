@@ -144,6 +144,10 @@ int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* 
                           int accumulate, hipStream_t s);
 int tiled_geometry(int variant, int* rows_per_tile, int* cols_per_block, int* bundle_capacity);
 int tiled_max_blocks_per_tile();
+constexpr int MODEL_CONVS = 5;   // convs of GNNModel that are used (gconv3_s2w is not)
+int launch_param_prep_batch(int n, const float* const* conv_params, const int* cin, float* const* derived, hipStream_t s);
+int launch_finalize_batch(int n, const float* const* conv_params, const int* cin, const float* const* stats,
+                          const int* n_stat_blocks, float* const* grads, float* zero, int n_zero, hipStream_t s);
 int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s);
 int launch_node_qp(const float* x_dst, int64_t n_dst, const float* derived, float* qp, float* t, hipStream_t s);
 int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const ConvWs& w, const float* x_src,

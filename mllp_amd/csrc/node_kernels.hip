@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // -------------------------------------------------------------------------------------------------
 // param_prep: one workgroup per conv
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void param_prep_kernel(ConvParams p, int cin, float* __restrict__ D) {
+__device__ __forceinline__ void param_prep_body(const ConvParams& p, int cin, float* __restrict__ D) {
     const int tid = threadIdx.x;
     const int k = tid >> 4, d = tid & 15;
     float pq = 0.0f, wst = 0.0f, wvt = 0.0f;
@@ -53,6 +53,33 @@ __global__ __launch_bounds__(BLOCK) void param_prep_kernel(ConvParams p, int cin
         D[OFF_PB + tid] = 0.25f * pb;
         D[OFF_PT0 + tid] = 0.25f * pt0;
     }
+}
+
+__global__ __launch_bounds__(BLOCK) void param_prep_kernel(ConvParams p, int cin, float* __restrict__ D) {
+    param_prep_body(p, cin, D);
+}
+
+// all convs of the model in one launch (workgroup = conv): four launches fewer on the forward critical path
+struct PrepBatch {
+    ConvParams p[MODEL_CONVS];
+    int cin[MODEL_CONVS];
+    float* D[MODEL_CONVS];
+};
+__global__ __launch_bounds__(BLOCK) void param_prep_batch_kernel(PrepBatch b) {
+    param_prep_body(b.p[blockIdx.x], b.cin[blockIdx.x], b.D[blockIdx.x]);
+}
+
+int launch_param_prep_batch(int n, const float* const* conv_params, const int* cin, float* const* derived, hipStream_t s) {
+    if (n < 1 || n > MODEL_CONVS) return fail(MLLP_EINVAL, "param_prep_batch: conv count");
+    PrepBatch b;
+    for (int i = 0; i < n; ++i) {
+        b.p[i] = conv_params_at(conv_params[i], cin[i]);
+        b.cin[i] = cin[i];
+        b.D[i] = derived[i];
+    }
+    hipLaunchKernelGGL(param_prep_batch_kernel, dim3(n), dim3(BLOCK), 0, s, b);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "param_prep_batch");
 }
 
 int launch_param_prep(const float* conv_params, int cin, float* derived, hipStream_t s) {
@@ -315,8 +342,8 @@ int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_d
 // finalize_conv: fixed-order sum of the per-workgroup partial tiles, then the small matrix algebra
 // (oracle/spmm_form.py::conv_bwd "grads = {...}").  One workgroup.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void finalize_conv_kernel(int cin, ConvParams p, const float* __restrict__ stats,
-                                                             int nblk, float* __restrict__ grads) {
+__device__ __forceinline__ void finalize_conv_body(int cin, const ConvParams& p, const float* __restrict__ stats,
+                                                   int nblk, float* __restrict__ grads) {
     __shared__ float P[4][STAT_FLOATS];
     __shared__ float T[STAT_FLOATS];
     {
@@ -372,6 +399,49 @@ __global__ __launch_bounds__(1024) void finalize_conv_kernel(int cin, ConvParams
         gwe[c] = T2[c * 16 + 2] + 0.25f * we;
         gbq[c] = 0.25f * bq;
     }
+}
+
+__global__ __launch_bounds__(1024) void finalize_conv_kernel(int cin, ConvParams p, const float* __restrict__ stats,
+                                                             int nblk, float* __restrict__ grads) {
+    finalize_conv_body(cin, p, stats, nblk, grads);
+}
+
+// all convs of the model in one launch (workgroup = conv) + one workgroup that zeroes a gradient range (the
+// never-used gconv3_s2w): the single-workgroup tail of the step shrinks from five launches on two streams to one
+struct FinalizeBatch {
+    ConvParams p[MODEL_CONVS];
+    int cin[MODEL_CONVS];
+    const float* stats[MODEL_CONVS];
+    int nblk[MODEL_CONVS];
+    float* grads[MODEL_CONVS];
+    float* zero;
+    int n_zero;
+};
+__global__ __launch_bounds__(1024) void finalize_batch_kernel(FinalizeBatch b, int n) {
+    const int i = blockIdx.x;
+    if (i < n) {
+        finalize_conv_body(b.cin[i], b.p[i], b.stats[i], b.nblk[i], b.grads[i]);
+    } else {
+        for (int k = threadIdx.x; k < b.n_zero; k += 1024) b.zero[k] = 0.0f;
+    }
+}
+
+int launch_finalize_batch(int n, const float* const* conv_params, const int* cin, const float* const* stats,
+                          const int* n_stat_blocks, float* const* grads, float* zero, int n_zero, hipStream_t s) {
+    if (n < 1 || n > MODEL_CONVS) return fail(MLLP_EINVAL, "finalize_batch: conv count");
+    FinalizeBatch b;
+    for (int i = 0; i < n; ++i) {
+        b.p[i] = conv_params_at(conv_params[i], cin[i]);
+        b.cin[i] = cin[i];
+        b.stats[i] = stats[i];
+        b.nblk[i] = n_stat_blocks[i];
+        b.grads[i] = grads[i];
+    }
+    b.zero = zero;
+    b.n_zero = n_zero;
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(n + (n_zero > 0 ? 1 : 0)), dim3(1024), 0, s, b, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "finalize_batch");
 }
 
 int launch_finalize_conv(int cin, const float* conv_params, const float* stats, int n_stat_blocks, float* grads,

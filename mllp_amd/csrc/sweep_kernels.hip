@@ -66,7 +66,10 @@ static OrientDev make_dev(const Orient& o) {
 template <class Op, int UA, int UB>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, OrientDev o, float* __restrict__ scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x;
+    // workgroups are dispatched in blockIdx order: the long rows (wave and chunk tiers) go first so that they run
+    // next to the mass of short rows instead of forming the tail of the kernel
+    const int heavy = o.nbB + o.n_chunk;
+    const int b = (int)blockIdx.x < heavy ? (int)blockIdx.x + o.nbA : (int)blockIdx.x - heavy;
     if (b < o.nbA) {
         const int tile = xcd_tile(b, o.nbA);
         const int row = tile * 16 + wave * 4 + (lane >> 4);
@@ -78,7 +81,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename Op::Args args, Or
         if (row < o.n_dst && end - beg <= o.tier_wave) {   // longer rows belong to the wave / chunk tiers
             Op op;
             op.load_row(args, row, end - beg, lane & 15);
-            op.template edges<16, UA>(args, o, beg, end, 0, (16 / Op::LPN) * UA, lane & 15);
+            // one nonzero slot per pass suits the short rows that dominate real LPs (every unrolled slot is executed
+            // even when masked off), but a 40-nonzero row then takes 10 dependent passes and its wave becomes the
+            // tail: waves that hold such a row take UB slots per pass, like the wave tier
+            if (UA == 1 && UB > 1 && __any(end - beg > 2 * (16 / Op::LPN)))
+                op.template edges<16, UB>(args, o, beg, end, 0, (16 / Op::LPN) * UB, lane & 15);
+            else
+                op.template edges<16, UA>(args, o, beg, end, 0, (16 / Op::LPN) * UA, lane & 15);
             op.template reduce<16>();
             op.epilogue(args, row, end - beg, lane & 15);
         }

@@ -351,7 +351,23 @@ __device__ __forceinline__ void finalize_conv_body(int cin, const ConvParams& p,
         float v[STAT_TILES];
 #pragma unroll
         for (int i = 0; i < STAT_TILES; ++i) v[i] = 0.0f;
-        for (int b = slice; b < nblk; b += 4) {      // 7 independent loads per pass
+        // fixed order b = slice, slice + 4, ...; four partials (28 independent loads) in flight per thread: the sum is
+        // bound by memory round trips, not by the additions
+        int b = slice;
+        for (; b + 12 < nblk; b += 16) {
+            float t0[STAT_TILES], t1[STAT_TILES], t2[STAT_TILES], t3[STAT_TILES];
+            const float* src = stats + (size_t)b * STAT_FLOATS + col;
+#pragma unroll
+            for (int i = 0; i < STAT_TILES; ++i) {
+                t0[i] = src[i * 256];
+                t1[i] = src[(size_t)4 * STAT_FLOATS + i * 256];
+                t2[i] = src[(size_t)8 * STAT_FLOATS + i * 256];
+                t3[i] = src[(size_t)12 * STAT_FLOATS + i * 256];
+            }
+#pragma unroll
+            for (int i = 0; i < STAT_TILES; ++i) v[i] = (((v[i] + t0[i]) + t1[i]) + t2[i]) + t3[i];
+        }
+        for (; b < nblk; b += 4) {
             const float* src = stats + (size_t)b * STAT_FLOATS + col;
 #pragma unroll
             for (int i = 0; i < STAT_TILES; ++i) v[i] += src[i * 256];
@@ -513,8 +529,15 @@ __global__ __launch_bounds__(BLOCK) void head_finalize_kernel(const float* __res
     __shared__ float sh[8][32];
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
     float v = 0.0f;
-    if (col < 18)
-        for (int b = slice; b < nblk; b += 8) v += partials[(size_t)b * 18 + col];
+    if (col < 18) {
+        int b = slice;
+        for (; b + 24 < nblk; b += 32) {      // four loads in flight, fixed order
+            const float t0 = partials[(size_t)b * 18 + col], t1 = partials[(size_t)(b + 8) * 18 + col];
+            const float t2 = partials[(size_t)(b + 16) * 18 + col], t3 = partials[(size_t)(b + 24) * 18 + col];
+            v = (((v + t0) + t1) + t2) + t3;
+        }
+        for (; b < nblk; b += 8) v += partials[(size_t)b * 18 + col];
+    }
     sh[slice][col] = v;
     __syncthreads();
     if (threadIdx.x < 18) {

@@ -6,6 +6,7 @@
 CSR(A) + CSR(A^T) behind an opaque `mllp_graph_t*`, and every model call takes it by handle.
 """
 import ctypes
+import os
 from ctypes import c_int32, c_int64, c_double, c_void_p
 from typing import List, Optional, Sequence
 
@@ -135,27 +136,68 @@ class LPBatch:
         del key, inv, is_start
         # Order of the entries inside a (row, block) run.  A ds_read_b128 serves 16 lanes = 4 quads per LDS cycle and a
         # 64-byte H row covers a quarter of the 256-byte bank row, so four quads reading H rows with equal
-        # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).  The quad that owns sorted position k sits in slot
-        # g = ((k mod 16) mod 8) >> 1 of its lane group; its p-th entry should have column class (g + p) mod 4, so
-        # that the four quads of a group hit four different quarters: round-robin over the classes, starting at g.
+        # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).
         cls = ((idx - blk * CB) & 3).long()
-        g = ((pos_key & 7) >> 1)
-        rank = torch.zeros(nnz, dtype=torch.int64, device=dev)
-        for c in range(4):
-            ind = (cls == c).long()
-            ex = torch.cumsum(ind, 0) - ind                      # entries of class c before this one
-            rank = torch.where(cls == c, ex - ex[start_idx], rank)
-            del ind, ex
-        k2 = rank * 4 + ((cls - g) & 3)
-        del rank, cls, g
-        K = int(k2.max()) + 1
-        ordr = torch.argsort(start_idx * K + k2)                 # runs stay contiguous; inside a run by k2
-        del k2
-        new_off = torch.empty(nnz, dtype=torch.int64, device=dev)
-        new_off[ordr] = ar
-        del ordr
-        dest = ptr2[pos_key] + (new_off - start_idx)
-        del ar, start_idx, pos_key, new_off
+        joint = int(variant) in (0, 1) and R % 16 == 0 and os.environ.get("MLLP_TILED_ORDER", "joint") != "perrow"
+        if joint:
+            # JOINT ordering of the four rows whose quads share a lane group ({0,3,5,6}, {1,2,4,7}, {8,11,13,14},
+            # {9,10,12,15} of the 16 quads that walk positions 16 b .. 16 b + 15): at step p the four rows should
+            # present four different column classes.  Greedy per step, the row that chooses first rotates with p;
+            # a row takes its most numerous class that is still free (simulated: 2.05 random, 1.76 per-row
+            # round-robin, 1.42 LDS cycles per step with this).
+            n_run = n_tb * R
+            cnt = torch.zeros(n_run * 4, dtype=torch.int32, device=dev)
+            cnt.index_add_(0, pos_key * 4 + cls, torch.ones(nnz, dtype=torch.int32, device=dev))
+            base = torch.cumsum(cnt, 0, dtype=torch.int64) - cnt              # start of (run, class) in canonical order
+            order_c = torch.argsort(pos_key * 4 + cls, stable=True)            # canonical: (run, class, column)
+            QG = torch.tensor([[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]], device=dev)
+            c = cnt.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()          # [G, slot, class]
+            bs = base.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()
+            p2 = ptr2[:-1].view(n_tb, R // 16, 16)[:, :, QG].reshape(-1, 4).contiguous()         # first slot of each run
+            del cnt, base
+            c0 = c.clone()
+            rem = c.sum(-1)
+            maxlen = int(rem.max())
+            joint = maxlen <= 512                                             # pathological rows: per-row ordering below
+        if joint:
+            dest = torch.empty(nnz, dtype=torch.int64, device=dev)
+            for p in range(maxlen):
+                used = torch.zeros((c.shape[0], 4), dtype=torch.bool, device=dev)
+                for j in range(4):
+                    i = (j + p) % 4
+                    ci = c[:, i, :]
+                    act = rem[:, i] > 0
+                    avail = (ci > 0) & ~used
+                    pick = torch.where(avail.any(1), torch.where(avail, ci, torch.full_like(ci, -1)).argmax(1), ci.argmax(1))
+                    pk = pick[:, None]
+                    occ = (c0[:, i, :].gather(1, pk) - ci.gather(1, pk)).squeeze(1).long()
+                    sel = act.nonzero().squeeze(1)
+                    src = order_c[(bs[:, i, :].gather(1, pk).squeeze(1) + occ)[sel]]
+                    dest[src] = p2[sel, i] + p
+                    ci.scatter_add_(1, pk, -act.to(ci.dtype)[:, None])
+                    rem[:, i] -= act.to(rem.dtype)
+                    used.scatter_(1, pk, used.gather(1, pk) | act[:, None])
+            del c, c0, bs, p2, rem, order_c, used, cls, ar, start_idx
+        else:
+            # per-row ordering: round-robin over the classes, starting at the slot of the row's quad in its lane group
+            g = ((pos_key & 7) >> 1)
+            rank = torch.zeros(nnz, dtype=torch.int64, device=dev)
+            for cc in range(4):
+                ind = (cls == cc).long()
+                ex = torch.cumsum(ind, 0) - ind                      # entries of class cc before this one
+                rank = torch.where(cls == cc, ex - ex[start_idx], rank)
+                del ind, ex
+            k2 = rank * 4 + ((cls - g) & 3)
+            del rank, cls, g
+            K = int(k2.max()) + 1
+            ordr = torch.argsort(start_idx * K + k2)                 # runs stay contiguous; inside a run by k2
+            del k2
+            new_off = torch.empty(nnz, dtype=torch.int64, device=dev)
+            new_off[ordr] = ar
+            del ordr
+            dest = ptr2[pos_key] + (new_off - start_idx)
+            del ar, start_idx, new_off
+        del pos_key
         # one padding entry behind the last: an empty (tile, block) at the very end still has a readable "first entry"
         ent = torch.zeros((nnz + 1, 2), dtype=torch.int32, device=dev)
         # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records

@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--synthetic-instances", type=int, default=256, help="instances per GPU of the roofline batch")
     ap.add_argument("--synthetic-steps", type=int, default=5)
-    ap.add_argument("--spmm-reps", type=int, default=10)
+    ap.add_argument("--spmm-reps", type=int, default=30)
     ap.add_argument("--no-synthetic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hip-graph", action="store_true")
@@ -201,8 +201,8 @@ def main():
         ms_gat = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps)
         ref_a = Ym.clone()
         tiled_a, tiled_at = sb.enable_tiled(False), sb.enable_tiled(True)
-        ms_a = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps) if tiled_a else ms_ga
-        ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps) if tiled_at else ms_gat
+        ms_a = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps, warm=5) if tiled_a else ms_ga
+        ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps, warm=5) if tiled_at else ms_gat
         tiled_err = float((Ym - ref_a).abs().max() / ref_a.abs().max())
         gbs_a, gbs_at = b_a / ms_a / 1e6, b_at / ms_at / 1e6
         kernels = [

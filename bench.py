@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--synthetic-instances", type=int, default=256, help="instances per GPU of the roofline batch")
-    ap.add_argument("--synthetic-steps", type=int, default=5)
+    ap.add_argument("--synthetic-steps", type=int, default=10)
     ap.add_argument("--spmm-reps", type=int, default=30)
     ap.add_argument("--no-synthetic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,11 +225,11 @@ def main():
         # forward bytes: pattern + source rows once + per destination: node_qp (x read, q' and t written) and the
         # sweep (q', t, x read; h, Z, aux written) = 132 + 132 + 144 = 408 B
         b_f = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 64 + sb.M * 408
-        ms_fg = timed(conv_f, 3, warm=1)
+        ms_fg = timed(conv_f, 10, warm=3)
         kernels.append({"kernel": "tconv_fwd16 generic (prep + node_qp + attention sweep from L2), dst=constraints",
                         "ms": ms_fg, "alg_bytes": b_f, "GBps": b_f / ms_fg / 1e6, "frac": b_f / ms_fg / 1e6 / HBM_PEAK_GBS})
         if sb.enable_tiled(False, variant=1) and sb.enable_tiled(True, variant=1):
-            ms_ft = timed(conv_f, 3, warm=1)
+            ms_ft = timed(conv_f, 10, warm=3)
             kernels.append({"kernel": "tconv_fwd16 LDS-tiled (prep + node_qp + fwd16_tiled_kernel), dst=constraints",
                             "ms": ms_ft, "alg_bytes": b_f, "GBps": b_f / ms_ft / 1e6,
                             "frac": b_f / ms_ft / 1e6 / HBM_PEAK_GBS})
@@ -242,11 +242,11 @@ def main():
         def conv_b():
             sb.tconv_bwd(False, 16, cp, Hn, Hm, h[0], ws, dh)
         conv_f()
-        ms_bg = timed(conv_b, 3, warm=1)
+        ms_bg = timed(conv_b, 6, warm=2)
         kernels.append({"kernel": "tconv_bwd16 generic (bwd_pre + dst sweep + src gather sweep + stats), dst=constraints",
                         "ms": ms_bg, "alg_bytes": b_b, "GBps": b_b / ms_bg / 1e6, "frac": b_b / ms_bg / 1e6 / HBM_PEAK_GBS})
         if sb.enable_tiled(True, variant=2) and sb.enable_tiled(False, variant=2):
-            ms_bt = timed(conv_b, 3, warm=1)
+            ms_bt = timed(conv_b, 6, warm=2)
             kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel, dst=constraints",
                             "ms": ms_bt, "alg_bytes": b_b, "GBps": b_b / ms_bt / 1e6,
                             "frac": b_b / ms_bt / 1e6 / HBM_PEAK_GBS})
@@ -256,11 +256,11 @@ def main():
         x1s, x1d = torch.randn(sb.N, device="cuda"), torch.randn(sb.M, device="cuda")
         ws1 = sb.tconv_workspace(False, 1)
         b_f1 = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 4 + sb.M * (4 + 64 + 4 + 16)
-        ms_1g = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 3, warm=1)
+        ms_1g = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
         kernels.append({"kernel": "tconv_fwd1 generic (lane per nonzero, 4-byte gathers from L2), dst=constraints",
                         "ms": ms_1g, "alg_bytes": b_f1, "GBps": b_f1 / ms_1g / 1e6, "frac": b_f1 / ms_1g / 1e6 / HBM_PEAK_GBS})
         if sb.enable_tiled(False, variant=3) and sb.enable_tiled(True, variant=3):
-            ms_1t = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 3, warm=1)
+            ms_1t = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
             kernels.append({"kernel": "tconv_fwd1 LDS-tiled (scalar_tiled_kernel, lane per row), dst=constraints",
                             "ms": ms_1t, "alg_bytes": b_f1, "GBps": b_f1 / ms_1t / 1e6,
                             "frac": b_f1 / ms_1t / 1e6 / HBM_PEAK_GBS})

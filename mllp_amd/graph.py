@@ -17,6 +17,131 @@ from . import _lib
 from .data import LPInstance
 
 
+def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0):
+    """Re-block one CSR orientation into the tiled layout of include/mllp_hip.h (mllp_graph_attach_tiled): row tiles
+    of R rows x column blocks of CB columns, rows of a (tile, block) ordered by their entry count, entries of the
+    four rows of a ds_read_b128 lane group ordered jointly over (column mod 4).  Pure torch, any device (the CPU
+    tests check it against the CSR it came from).  Returns (arrays, info) or None when the matrix does not qualify."""
+    dev, nnz = idx.device, int(idx.numel())
+    if nnz == 0:
+        return None
+    n_tiles = (n_dst + R - 1) // R
+    deg = (ptr[1:] - ptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n_dst, device=dev, dtype=torch.int32), deg)
+    tile = torch.div(rows, R, rounding_mode="floor")
+    blk = torch.div(idx, CB, rounding_mode="floor")
+    tl = tile.long()
+    lo = torch.full((n_tiles,), 2 ** 30, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amin")
+    hi = torch.full((n_tiles,), -1, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amax")
+    nbt = torch.where(hi >= 0, hi - lo + 1, torch.zeros_like(hi)).long()
+    lo = torch.where(hi >= 0, lo, torch.zeros_like(lo))
+    tile_blk = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
+    tile_blk[1:] = torch.cumsum(nbt, 0)
+    n_tb = int(tile_blk[-1])
+    max_nbt = int(nbt.max())
+    if n_tb * R >= 2 ** 31 - 1 or max_nbt > 255:
+        return None
+    key = (tile_blk[tl] + (blk - lo[tl]).long()) * R + (rows - tile * R).long()
+    del rows, tile, tl
+    counts = torch.bincount(key, minlength=n_tb * R)
+    # inside every (tile, block): rows ordered by their entry count, descending (stable)
+    order = torch.argsort(counts.view(n_tb, R), dim=1, descending=True, stable=True)       # [n_tb, R] row of position k
+    inv = torch.empty_like(order)
+    inv.scatter_(1, order, torch.arange(R, device=dev).expand(n_tb, R))                    # position of row r
+    sorted_counts = torch.gather(counts.view(n_tb, R), 1, order).reshape(-1)
+    del counts
+    ptr2 = torch.zeros(n_tb * R + 1, dtype=torch.int64, device=dev)
+    ptr2[1:] = torch.cumsum(sorted_counts, 0)
+    del sorted_counts
+    max_run = int((ptr2[R::R] - ptr2[:-1:R]).max())     # longest (tile, block) segment (informational)
+    ar = torch.arange(nnz, device=dev, dtype=torch.int64)
+    is_start = torch.ones(nnz, dtype=torch.bool, device=dev)
+    is_start[1:] = key[1:] != key[:-1]
+    start_idx = torch.cummax(torch.where(is_start, ar, torch.zeros_like(ar)), 0)[0]
+    pos_key = torch.div(key, R, rounding_mode="floor") * R + inv.reshape(-1)[key]          # (tb, sorted position)
+    del key, inv, is_start
+    # Order of the entries inside a (row, block) run.  A ds_read_b128 serves 16 lanes = 4 quads per LDS cycle and a
+    # 64-byte H row covers a quarter of the 256-byte bank row, so four quads reading H rows with equal
+    # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).
+    cls = ((idx - blk * CB) & 3).long()
+    joint = int(variant) in (0, 1) and R % 16 == 0 and os.environ.get("MLLP_TILED_ORDER", "joint") != "perrow"
+    if joint:
+        # JOINT ordering of the four rows whose quads share a lane group ({0,3,5,6}, {1,2,4,7}, {8,11,13,14},
+        # {9,10,12,15} of the 16 quads that walk positions 16 b .. 16 b + 15): at step p the four rows should
+        # present four different column classes.  Greedy per step, the row that chooses first rotates with p;
+        # a row takes its most numerous class that is still free (simulated: 2.05 random, 1.76 per-row
+        # round-robin, 1.42 LDS cycles per step with this).
+        n_run = n_tb * R
+        cnt = torch.zeros(n_run * 4, dtype=torch.int32, device=dev)
+        cnt.index_add_(0, pos_key * 4 + cls, torch.ones(nnz, dtype=torch.int32, device=dev))
+        base = torch.cumsum(cnt, 0, dtype=torch.int64) - cnt              # start of (run, class) in canonical order
+        order_c = torch.argsort(pos_key * 4 + cls, stable=True)            # canonical: (run, class, column)
+        QG = torch.tensor([[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]], device=dev)
+        c = cnt.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()          # [G, slot, class]
+        bs = base.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()
+        p2 = ptr2[:-1].view(n_tb, R // 16, 16)[:, :, QG].reshape(-1, 4).contiguous()         # first slot of each run
+        del cnt, base
+        c0 = c.clone()
+        rem = c.sum(-1)
+        maxlen = int(rem.max())
+        joint = maxlen <= 512                                             # pathological rows: per-row ordering below
+    if joint:
+        dest = torch.empty(nnz, dtype=torch.int64, device=dev)
+        for p in range(maxlen):
+            used = torch.zeros((c.shape[0], 4), dtype=torch.bool, device=dev)
+            for j in range(4):
+                i = (j + p) % 4
+                ci = c[:, i, :]
+                act = rem[:, i] > 0
+                avail = (ci > 0) & ~used
+                pick = torch.where(avail.any(1), torch.where(avail, ci, torch.full_like(ci, -1)).argmax(1), ci.argmax(1))
+                pk = pick[:, None]
+                occ = (c0[:, i, :].gather(1, pk) - ci.gather(1, pk)).squeeze(1).long()
+                sel = act.nonzero().squeeze(1)
+                src = order_c[(bs[:, i, :].gather(1, pk).squeeze(1) + occ)[sel]]
+                dest[src] = p2[sel, i] + p
+                ci.scatter_add_(1, pk, -act.to(ci.dtype)[:, None])
+                rem[:, i] -= act.to(rem.dtype)
+                used.scatter_(1, pk, used.gather(1, pk) | act[:, None])
+        del c, c0, bs, p2, rem, order_c, used, cls, ar, start_idx
+    else:
+        # per-row ordering: round-robin over the classes, starting at the slot of the row's quad in its lane group
+        g = ((pos_key & 7) >> 1)
+        rank = torch.zeros(nnz, dtype=torch.int64, device=dev)
+        for cc in range(4):
+            ind = (cls == cc).long()
+            ex = torch.cumsum(ind, 0) - ind                      # entries of class cc before this one
+            rank = torch.where(cls == cc, ex - ex[start_idx], rank)
+            del ind, ex
+        k2 = rank * 4 + ((cls - g) & 3)
+        del rank, cls, g
+        K = int(k2.max()) + 1
+        ordr = torch.argsort(start_idx * K + k2)                 # runs stay contiguous; inside a run by k2
+        del k2
+        new_off = torch.empty(nnz, dtype=torch.int64, device=dev)
+        new_off[ordr] = ar
+        del ordr
+        dest = ptr2[pos_key] + (new_off - start_idx)
+        del ar, start_idx, new_off
+    del pos_key
+    # one padding entry behind the last: an empty (tile, block) at the very end still has a readable "first entry"
+    ent = torch.zeros((nnz + 1, 2), dtype=torch.int32, device=dev)
+    # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records
+    # (variant 2) or 4-byte scalars (variant 3)
+    ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4, 4: 64}[int(variant)]
+    ent[dest, 1] = val.view(torch.int32)
+    del dest, blk
+    perm = order.reshape(-1).to(torch.int32).contiguous()
+    del order
+    owner = torch.repeat_interleave(torch.arange(n_tiles, device=dev), nbt)
+    blk_id = (lo[owner].long() + (torch.arange(n_tb, device=dev) - tile_blk[owner])).to(torch.int32)
+    keep = dict(tile_blk=tile_blk.to(torch.int32).contiguous(), blk_id=blk_id.contiguous(),
+                ptr2=ptr2.to(torch.int32).contiguous(), perm=perm, ent=ent.contiguous())
+    info = dict(rows_per_tile=R, cols_per_block=CB, n_tiles=n_tiles, n_tb=n_tb, max_nbt=max_nbt, max_run=max_run,
+                staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
+    return keep, info
+
+
 class LPBatch:
     def __init__(self, handle, M, N, nnz, n_inst, inst_m, inst_n, x1, x2, labels, names=None):
         self._h = handle
@@ -96,121 +221,11 @@ class LPBatch:
         R, CB, CAP = R.value, CB.value, CAP.value
         ptr, idx, val = arrays if arrays is not None else self._device_orientation(transpose)
         n_dst = self.N if transpose else self.M
-        dev, nnz = idx.device, int(idx.numel())
-        if nnz == 0:
+        built = build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant)
+        if built is None:
             return None
-        n_tiles = (n_dst + R - 1) // R
-        deg = (ptr[1:] - ptr[:-1]).long()
-        rows = torch.repeat_interleave(torch.arange(n_dst, device=dev, dtype=torch.int32), deg)
-        tile = torch.div(rows, R, rounding_mode="floor")
-        blk = torch.div(idx, CB, rounding_mode="floor")
-        tl = tile.long()
-        lo = torch.full((n_tiles,), 2 ** 30, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amin")
-        hi = torch.full((n_tiles,), -1, dtype=torch.int32, device=dev).scatter_reduce(0, tl, blk, "amax")
-        nbt = torch.where(hi >= 0, hi - lo + 1, torch.zeros_like(hi)).long()
-        lo = torch.where(hi >= 0, lo, torch.zeros_like(lo))
-        tile_blk = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
-        tile_blk[1:] = torch.cumsum(nbt, 0)
-        n_tb = int(tile_blk[-1])
-        max_nbt = int(nbt.max())
-        if n_tb * R >= 2 ** 31 - 1 or max_nbt > 255:
-            return None
-        key = (tile_blk[tl] + (blk - lo[tl]).long()) * R + (rows - tile * R).long()
-        del rows, tile, tl
-        counts = torch.bincount(key, minlength=n_tb * R)
-        # inside every (tile, block): rows ordered by their entry count, descending (stable)
-        order = torch.argsort(counts.view(n_tb, R), dim=1, descending=True, stable=True)       # [n_tb, R] row of position k
-        inv = torch.empty_like(order)
-        inv.scatter_(1, order, torch.arange(R, device=dev).expand(n_tb, R))                    # position of row r
-        sorted_counts = torch.gather(counts.view(n_tb, R), 1, order).reshape(-1)
-        del counts
-        ptr2 = torch.zeros(n_tb * R + 1, dtype=torch.int64, device=dev)
-        ptr2[1:] = torch.cumsum(sorted_counts, 0)
-        del sorted_counts
-        max_run = int((ptr2[R::R] - ptr2[:-1:R]).max())     # longest (tile, block) segment (informational)
-        ar = torch.arange(nnz, device=dev, dtype=torch.int64)
-        is_start = torch.ones(nnz, dtype=torch.bool, device=dev)
-        is_start[1:] = key[1:] != key[:-1]
-        start_idx = torch.cummax(torch.where(is_start, ar, torch.zeros_like(ar)), 0)[0]
-        pos_key = torch.div(key, R, rounding_mode="floor") * R + inv.reshape(-1)[key]          # (tb, sorted position)
-        del key, inv, is_start
-        # Order of the entries inside a (row, block) run.  A ds_read_b128 serves 16 lanes = 4 quads per LDS cycle and a
-        # 64-byte H row covers a quarter of the 256-byte bank row, so four quads reading H rows with equal
-        # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).
-        cls = ((idx - blk * CB) & 3).long()
-        joint = int(variant) in (0, 1) and R % 16 == 0 and os.environ.get("MLLP_TILED_ORDER", "joint") != "perrow"
-        if joint:
-            # JOINT ordering of the four rows whose quads share a lane group ({0,3,5,6}, {1,2,4,7}, {8,11,13,14},
-            # {9,10,12,15} of the 16 quads that walk positions 16 b .. 16 b + 15): at step p the four rows should
-            # present four different column classes.  Greedy per step, the row that chooses first rotates with p;
-            # a row takes its most numerous class that is still free (simulated: 2.05 random, 1.76 per-row
-            # round-robin, 1.42 LDS cycles per step with this).
-            n_run = n_tb * R
-            cnt = torch.zeros(n_run * 4, dtype=torch.int32, device=dev)
-            cnt.index_add_(0, pos_key * 4 + cls, torch.ones(nnz, dtype=torch.int32, device=dev))
-            base = torch.cumsum(cnt, 0, dtype=torch.int64) - cnt              # start of (run, class) in canonical order
-            order_c = torch.argsort(pos_key * 4 + cls, stable=True)            # canonical: (run, class, column)
-            QG = torch.tensor([[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]], device=dev)
-            c = cnt.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()          # [G, slot, class]
-            bs = base.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()
-            p2 = ptr2[:-1].view(n_tb, R // 16, 16)[:, :, QG].reshape(-1, 4).contiguous()         # first slot of each run
-            del cnt, base
-            c0 = c.clone()
-            rem = c.sum(-1)
-            maxlen = int(rem.max())
-            joint = maxlen <= 512                                             # pathological rows: per-row ordering below
-        if joint:
-            dest = torch.empty(nnz, dtype=torch.int64, device=dev)
-            for p in range(maxlen):
-                used = torch.zeros((c.shape[0], 4), dtype=torch.bool, device=dev)
-                for j in range(4):
-                    i = (j + p) % 4
-                    ci = c[:, i, :]
-                    act = rem[:, i] > 0
-                    avail = (ci > 0) & ~used
-                    pick = torch.where(avail.any(1), torch.where(avail, ci, torch.full_like(ci, -1)).argmax(1), ci.argmax(1))
-                    pk = pick[:, None]
-                    occ = (c0[:, i, :].gather(1, pk) - ci.gather(1, pk)).squeeze(1).long()
-                    sel = act.nonzero().squeeze(1)
-                    src = order_c[(bs[:, i, :].gather(1, pk).squeeze(1) + occ)[sel]]
-                    dest[src] = p2[sel, i] + p
-                    ci.scatter_add_(1, pk, -act.to(ci.dtype)[:, None])
-                    rem[:, i] -= act.to(rem.dtype)
-                    used.scatter_(1, pk, used.gather(1, pk) | act[:, None])
-            del c, c0, bs, p2, rem, order_c, used, cls, ar, start_idx
-        else:
-            # per-row ordering: round-robin over the classes, starting at the slot of the row's quad in its lane group
-            g = ((pos_key & 7) >> 1)
-            rank = torch.zeros(nnz, dtype=torch.int64, device=dev)
-            for cc in range(4):
-                ind = (cls == cc).long()
-                ex = torch.cumsum(ind, 0) - ind                      # entries of class cc before this one
-                rank = torch.where(cls == cc, ex - ex[start_idx], rank)
-                del ind, ex
-            k2 = rank * 4 + ((cls - g) & 3)
-            del rank, cls, g
-            K = int(k2.max()) + 1
-            ordr = torch.argsort(start_idx * K + k2)                 # runs stay contiguous; inside a run by k2
-            del k2
-            new_off = torch.empty(nnz, dtype=torch.int64, device=dev)
-            new_off[ordr] = ar
-            del ordr
-            dest = ptr2[pos_key] + (new_off - start_idx)
-            del ar, start_idx, new_off
-        del pos_key
-        # one padding entry behind the last: an empty (tile, block) at the very end still has a readable "first entry"
-        ent = torch.zeros((nnz + 1, 2), dtype=torch.int32, device=dev)
-        # byte offset of the column's staged item inside the block: 64-byte feature rows, 160-byte backward records
-        # (variant 2) or 4-byte scalars (variant 3)
-        ent[dest, 0] = (idx - blk * CB) * {0: 64, 1: 64, 2: 160, 3: 4, 4: 64}[int(variant)]
-        ent[dest, 1] = val.view(torch.int32)
-        del dest, blk
-        perm = order.reshape(-1).to(torch.int32).contiguous()
-        del order
-        owner = torch.repeat_interleave(torch.arange(n_tiles, device=dev), nbt)
-        blk_id = (lo[owner].long() + (torch.arange(n_tb, device=dev) - tile_blk[owner])).to(torch.int32)
-        keep = dict(tile_blk=tile_blk.to(torch.int32).contiguous(), blk_id=blk_id.contiguous(),
-                    ptr2=ptr2.to(torch.int32).contiguous(), perm=perm, ent=ent.contiguous())
+        keep, info = built
+        n_tiles, n_tb, max_nbt = info["n_tiles"], info["n_tb"], info.pop("max_nbt")
         torch.cuda.synchronize()
         _lib.check(L.mllp_graph_attach_tiled(self._h, int(transpose), int(variant), n_tiles, n_tb, max_nbt,
                                              _lib.ptr(keep["tile_blk"]),
@@ -219,8 +234,7 @@ class LPBatch:
         if not hasattr(self, "_tiled"):
             self._tiled = {}
         self._tiled[(bool(transpose), int(variant))] = keep          # the library borrows these arrays
-        return dict(rows_per_tile=R, cols_per_block=CB, n_tiles=n_tiles, n_tb=n_tb, max_run=max_run,
-                    staged_bytes=n_tb * CB * 64, gathered_bytes=nnz * 64)
+        return info
 
     def enable_tiled_all(self):
         """Attach every LDS-tiled copy (variants 0-3, both orientations; variant 4, the destination-major backward

@@ -209,3 +209,79 @@ def test_root_shims_and_driver_argument_errors(tmp_path, monkeypatch):
     y.write_text("train_data_type: 'twitch'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'gs-topk'\n")
     with pytest.raises(ValueError, match="Unknown training dataset"):
         experiment.main(["--cfg", str(y)])
+
+
+def _random_csr(rng, m, n, kmax):
+    rows = [np.sort(rng.choice(n, size=int(rng.integers(0, kmax)), replace=False)) for _ in range(m)]
+    ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    idx = np.concatenate(rows).astype(np.int32) if ptr[-1] else np.zeros(0, np.int32)
+    val = rng.standard_normal(len(idx)).astype(np.float32)
+    return ptr, idx, val
+
+
+@pytest.mark.parametrize("variant,R,CB,mult", [(0, 512, 1024, 64), (1, 512, 512, 64), (2, 512, 384, 160), (3, 256, 1024, 4),
+                                                (4, 256, 768, 64)])
+def test_tiled_reblocking_is_a_permutation_of_the_csr(variant, R, CB, mult):
+    """mllp_amd.graph.build_tiled_arrays (the layout mllp_graph_attach_tiled borrows): every nonzero appears exactly
+    once with its value, rows of a (tile, block) are ordered by entry count, offsets are consistent, entries carry the
+    byte offset of their column's staged item; ragged input (empty rows, a ragged last tile and last column block)."""
+    from mllp_amd.graph import build_tiled_arrays
+    rng = np.random.default_rng(11 + variant)
+    m, n = 1100, 2500
+    ptr, idx, val = _random_csr(rng, m, n, 40)
+    keep, info = build_tiled_arrays(torch.tensor(ptr), torch.tensor(idx), torch.tensor(val), m, R, CB, variant)
+    tile_blk, blk_id, ptr2, perm, ent = (keep[k].numpy() for k in ("tile_blk", "blk_id", "ptr2", "perm", "ent"))
+    n_tiles, n_tb = info["n_tiles"], info["n_tb"]
+    assert n_tiles == (m + R - 1) // R and tile_blk[0] == 0 and tile_blk[-1] == n_tb and len(blk_id) == n_tb
+    assert ptr2[0] == 0 and ptr2[-1] == len(idx) and np.all(np.diff(ptr2) >= 0) and len(perm) == n_tb * R
+    got = {}
+    for t in range(n_tiles):
+        for tb in range(tile_blk[t], tile_blk[t + 1]):
+            p = perm[tb * R:(tb + 1) * R]
+            assert sorted(p.tolist()) == list(range(R))                       # a permutation of the tile's rows
+            lens = np.diff(ptr2[tb * R:(tb + 1) * R + 1])
+            assert np.all(np.diff(lens) <= 0)                                 # longest rows first
+            for k in range(R):
+                row = t * R + int(p[k])
+                for e in range(ptr2[tb * R + k], ptr2[tb * R + k + 1]):
+                    off, bits = int(ent[e, 0]), ent[e, 1]
+                    assert off % mult == 0 and 0 <= off // mult < CB
+                    col = int(blk_id[tb]) * CB + off // mult
+                    assert row < m and (row, col) not in got
+                    got[(row, col)] = np.array([bits], np.int32).view(np.float32)[0]
+    want = {(r, int(idx[e])): val[e] for r in range(m) for e in range(ptr[r], ptr[r + 1])}
+    assert got.keys() == want.keys()
+    assert all(got[k] == want[k] for k in want)
+
+
+def test_tiled_joint_entry_order_spreads_bank_quarters():
+    """The joint ordering (variants 0 and 1) must beat the per-row ordering on the quantity it is built for: the
+    number of LDS cycles of a ds_read_b128 lane group = max multiplicity of (column mod 4) over its four quads."""
+    import os
+    from mllp_amd.graph import build_tiled_arrays
+    rng = np.random.default_rng(5)
+    m, n = 1024, 4096
+    ptr, idx, val = _random_csr(rng, m, n, 80)
+    QG = [[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]]
+
+    def cycles(keep, R):
+        ptr2, ent = keep["ptr2"].numpy(), keep["ent"].numpy()
+        n_tb = len(keep["blk_id"])
+        tot = steps = 0
+        for tb in range(n_tb):
+            for b in range(R // 16):
+                for grp in QG:
+                    runs = [ent[ptr2[tb * R + b * 16 + q]:ptr2[tb * R + b * 16 + q + 1], 0] // 64 % 4 for q in grp]
+                    for p in range(max(len(r) for r in runs)):
+                        cl = [int(r[p]) for r in runs if p < len(r)]
+                        tot += max(cl.count(c) for c in range(4))
+                        steps += 1
+        return tot / steps
+    args = (torch.tensor(ptr), torch.tensor(idx), torch.tensor(val), m, 512, 1024, 0)
+    joint = cycles(build_tiled_arrays(*args)[0], 512)
+    os.environ["MLLP_TILED_ORDER"] = "perrow"
+    try:
+        perrow = cycles(build_tiled_arrays(*args)[0], 512)
+    finally:
+        del os.environ["MLLP_TILED_ORDER"]
+    assert joint < perrow - 0.1 and joint < 1.6, (joint, perrow)

@@ -440,7 +440,9 @@ void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __rest
             // headers of both passes (offsets, rows, accumulators, first entries) are read up front, so the second
             // pass starts without dependent LDS round trips.  (Handing the pairs out from an LDS counter, longest
             // first, was slower and did not shorten the wait at the barrier.)
-            const int k0 = wave * 32 + quad, k1 = (2 * W_NW - 1 - wave) * 32 + quad;
+            // second bundle pair of each walker: measured per-pair costs (tools/phase_cycles.py) balanced by longest-
+            // processing-time assignment; the plain snake (15 - wave) left walker 4 the slowest by 5 %
+            const int k0 = wave * 32 + quad, k1 = (int)((0xADCE98BFu >> (4 * wave)) & 15u) * 32 + quad;
             const int2 hA0 = PP[k0], hA0n = PP[k0 + 1], hB0 = PP[k0 + 16], hB0n = PP[k0 + 17];
             const int2 hA1 = PP[k1], hA1n = PP[k1 + 1], hB1 = PP[k1 + 16], hB1n = PP[k1 + 17];
 #define W_ROWS(P)                                                                                           \

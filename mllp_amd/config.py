@@ -23,6 +23,7 @@ HOT_PATH_DEFAULTS = {
     "log_every": 1,          # print per-instance metrics every k epochs
     "save_every": 0,         # extra checkpoints every k epochs (0 == only at the end, as the reference)
     "resume": False,         # resume from linear_program_<data>_<method>.ckpt if present
+    "tiled_copies": "auto",  # LDS-tiled copies of the batch for the large-batch kernels: True | False | 'auto' (>= 32 M nonzeros)
     "use_hip_graph": "auto", # capture the training step into a hipGraph: True | False | 'auto' (= False: eager launches measured faster)
 }
 

@@ -69,7 +69,8 @@ def train_method(cfg, method_name, train_dataset, train_dict, out=print):
         b = LPBatch.from_instances([instances[i] for i in mine]) if mine else None
         batches.append((mine, b, len(grp)))
     trainer = LPTrainer(model.flat_parameters().detach(), lr=cfg.train_lr,
-                        use_hip_graph=cfg.get_default("use_hip_graph"), with_metrics=True)
+                        use_hip_graph=cfg.get_default("use_hip_graph"), with_metrics=True,
+                        tiled_copies=cfg.get_default("tiled_copies"))
     start_epoch = 0
     if cfg.get_default("resume") and os.path.exists(ckpt_path):
         ck = torch.load(ckpt_path, map_location=device, weights_only=True)

@@ -106,14 +106,19 @@ class LPTrainer:
     # `use_hip_graph=True` still forces capture.
     GRAPH_NNZ_LIMIT = 0
 
+    # "auto": batches of at least this many nonzeros get the LDS-tiled copies of both orientations (LPBatch.enable_tiled_all:
+    # the throughput regime of the library's row tiers starts at the same size); smaller ones use the generic sweeps
+    TILED_NNZ_MIN = 32 << 20
+
     def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph="auto",
-                 global_instances: Optional[int] = None, with_metrics=False):
+                 global_instances: Optional[int] = None, with_metrics=False, tiled_copies="auto"):
         assert params_flat.is_cuda and params_flat.numel() == NUM_PARAMS
         self.params = params_flat.detach().clone().float().contiguous()
         self.opt = FlatAdam(self.params, lr=lr)
         self.use_graph = use_hip_graph
         self.global_instances = global_instances
         self.with_metrics = with_metrics
+        self.tiled_copies = tiled_copies
         self._plans = {}
 
     def _plan(self, batch: LPBatch):
@@ -122,6 +127,9 @@ class LPTrainer:
         if p is None:
             dev = self.params.device
             graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
+            want_tiled = (batch.nnz >= self.TILED_NNZ_MIN) if self.tiled_copies == "auto" else bool(self.tiled_copies)
+            if want_tiled and not getattr(batch, "_tiled", None):
+                batch.enable_tiled_all()
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),
                      g_fwd=None, g_opt=None, warm=0, graph=graph)

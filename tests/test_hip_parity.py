@@ -619,3 +619,26 @@ def test_tiled_copies_edge_cases(LPBatch, weights):
     lb, lgb, gb = d.loss_step(flat_gpu)
     close(lgb.cpu().numpy(), lga.cpu().numpy(), 5e-6, "logits, multi-window segments")
     close(gb.cpu().numpy()[grad_mask()], ga.cpu().numpy()[grad_mask()], 5e-5, "grads, multi-window segments")
+
+
+def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
+    """LPTrainer(tiled_copies=True) attaches every tiled copy on first use (the `auto` policy does the same for
+    batches of >= 32 M nonzeros) and trains like the generic path: losses of three Adam steps agree."""
+    from mllp_amd.graph import synthetic_batch
+    from mllp_amd.trainer import LPTrainer
+    flat, sd, flat_gpu = weights
+    losses = {}
+    for mode in (False, True):
+        sb = synthetic_batch(n_inst=3, m=700, n=1300, mean_row_nnz=20.0, seed=77, chunk=1)
+        tr = LPTrainer(flat_gpu, lr=1e-3, use_hip_graph=False, tiled_copies=mode)
+        out = []
+        for _ in range(3):
+            loss, _ = tr.step(sb)
+            out.append(float(loss[0]))
+        assert bool(getattr(sb, "_tiled", None)) == mode
+        if mode:
+            assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (0, 1, 2, 3)]
+        losses[mode] = out
+    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-6, atol=0)
+    auto = LPTrainer(flat_gpu, tiled_copies="auto")
+    assert auto.TILED_NNZ_MIN == 32 << 20

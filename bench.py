@@ -7,15 +7,19 @@ of the CSR SpMM on the synthetic roofline batch (BASELINE.json metric).
       bench.py --gpus N --steps K --warmup W
 
 One JSON line on rank 0:
-  value        whole-job LP instances/s on the full Netlib batch (BASELINE.json configs[2], 97 instances,
-               one block-diagonal batch per rank and step, fp32), inputs resident in HBM, K steps timed
-               between barrier + synchronize pairs, max over ranks.  Weak scaling: every rank owns one
-               Netlib batch per step (97 instances per GPU), gradients all-reduced over RCCL each step.
+  value        whole-job LP instances/s on the full Netlib batch (BASELINE.json configs[2], 97 instances as
+               block-diagonal batches, fp32), inputs resident in HBM, K steps timed between barrier +
+               synchronize pairs, max over ranks.  `--scaling strong` (default): the 97 instances are SHARDED over
+               the ranks by nnz (trainer.shard_instances, as BASELINE.json's north_star words it), one Adam step per
+               global batch, gradients all-reduced over RCCL each step.  `--scaling weak`: every rank owns all 97.
+               With N > 1 the other mode is measured too and reported under "netlib_weak" / "netlib_strong".
   roofline     plain CSR SpMM  Y = A H  on the synthetic batch (configs[3]: m=10k, n=20k, ~1% dense,
                256 instances per GPU): algorithmic bytes / average launch duration, HIP events on the
                launch stream, against the 8 TB/s HBM3E peak.  `kernels` lists the other sweeps likewise.
   synthetic    LP instances/s of the full training step on that synthetic batch (configs[3]; with N
-               ranks it is configs[4]: 256 instances per GPU, weak scaling).
+               ranks 256 instances per GPU, weak scaling).
+  synthetic_strong  configs[4] as strong scaling: a FIXED global batch of 2048 instances per Adam step, as 8 / N
+               micro-batches of 256 per rank whose gradients are accumulated before the all-reduce.
   cpu_baseline the oracle's literal restatement of the reference loop (per-instance graph rebuild,
                forward, BCE, autograd backward, Adam; reference linear_program_experiment.py:120-144)
                timed on this host for one epoch of the same 97 instances (rank 0, N = 1 only).
@@ -50,6 +54,10 @@ def parse():
     ap.add_argument("--spmm-reps", type=int, default=30)
     ap.add_argument("--no-synthetic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="what `value` measures with N > 1 ranks: the 97 Netlib instances sharded over the ranks "
+                         "(strong) or replicated per rank (weak)")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads of the cpu_baseline leg")
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--hip-graph", default="auto", help="auto (capture only launch-bound batches) | True")
     return ap.parse_args()
@@ -91,7 +99,8 @@ def spmm_bytes(nnz, rows, cols, C=16):
 
 
 def load_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic.json), or None."""
+    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic.json), or None.  Counters need
+    rocprofv3 around the process, so this figure is NOT measured by this run: the JSON line says where it is from."""
     p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(p) as fh:
@@ -100,8 +109,9 @@ def load_traffic(kernel_key):
         return None
 
 
-def cpu_baseline(instances):
-    from oracle import pyg_restatement as o1
+def cpu_baseline(instances, threads):
+    from oracle import pyg_restatement as o1   # the ONLY use of the oracle in this file: the CPU leg
+    torch.set_num_threads(max(1, min(int(threads), os.cpu_count() or 1)))
     sd = o1.init_state(42, torch.float32)
     tr = o1.ReferenceTrainer(sd, lr=1e-3, dtype=torch.float32, rebuild_graph=True)
     small = sorted(instances, key=lambda i: i.nnz)[:3]
@@ -151,39 +161,80 @@ def main():
     from mllp_amd.data import load_packed
     from mllp_amd.graph import LPBatch, synthetic_batch
     from mllp_amd.trainer import LPTrainer
-    from oracle.pyg_restatement import flatten_state, init_state
+    from mllp_amd.model import GNNModel, set_seed
+    from mllp_amd.trainer import shard_instances
 
-    params0 = flatten_state(init_state(42, torch.float32)).cuda()
+    set_seed(42)                                    # reference linear_program_experiment.py:19
+    params0 = GNNModel().flat_parameters().detach().float().cuda()   # random init of the reference architecture
     instances = load_packed()
     n_inst = len(instances)
+    use_graph = False if args.no_hip_graph else args.hip_graph
+
+    def run_netlib(mode):
+        """K timed steps on the Netlib batch.  strong: this rank's nnz-balanced shard of the 97 instances, global
+        batch = 97; weak: all 97 on every rank, global batch = 97 * world.  One Adam step per global batch."""
+        if mode == "strong" and world > 1:
+            mine = shard_instances([i.nnz for i in instances], world)[rank]
+            total = n_inst
+        else:
+            mine = list(range(n_inst))
+            total = n_inst * world
+        batch = LPBatch.from_instances([instances[i] for i in mine]) if mine else None
+        trainer = LPTrainer(params0, lr=1e-3, use_hip_graph=use_graph, global_instances=total)
+
+        def one():
+            trainer.step(batch) if batch is not None else trainer.step_empty()
+        for _ in range(max(args.warmup, 2)):          # >= 2: eager pass + graph capture
+            one()
+        barrier_sync(dist_on)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one()
+        barrier_sync(dist_on)
+        dt = max_over_ranks(time.perf_counter() - t0, dist_on)
+        return dict(value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, scaling=mode,
+                    global_batch=total, instances_this_rank=len(mine), nnz_this_rank=batch.nnz if batch else 0,
+                    hip_graph=trainer.uses_graph(batch) if batch else False,
+                    final_loss_rank0=float(trainer.last_loss(batch)[0]) if batch else None)
 
     # ---------------- headline: Netlib batch, instances/s --------------------------------------
-    batch = LPBatch.from_instances(instances)
-    trainer = LPTrainer(params0, lr=1e-3, use_hip_graph=False if args.no_hip_graph else args.hip_graph,
-                        global_instances=n_inst * world)
-    for _ in range(max(args.warmup, 2)):          # >= 2: eager pass + graph capture
-        trainer.step(batch)
-    barrier_sync(dist_on)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(batch)
-    barrier_sync(dist_on)
-    dt = max_over_ranks(time.perf_counter() - t0, dist_on)
-    loss_end = float(trainer._plans[id(batch)]["loss"][0])
-    value = n_inst * world * args.steps / dt
+    head = run_netlib(args.scaling)
+    value = head["value"]
     out = {
         "metric": "LP instances/sec (fwd+bwd) on Netlib batch; achieved HBM GB/s on CSR SpMM",
         "value": value, "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "Netlib LP (97 normalized instances packed in data/netlib_norm.npz); "
                                 "synthetic sparse LPs for the roofline section",
-        "config": {"workload": "netlib_full: BASELINE.json configs[2], 97 instances / 1,074,147 nnz as one "
-                               "block-diagonal batch per GPU and step, fwd + BCE + bwd + Adam, fp32",
-                   "instances_per_gpu": n_inst, "nnz_per_gpu": batch.nnz,
-                   "hip_graph": bool(trainer._plans[id(batch)]["graph"]),
-                   "parallelism": f"dp{world}", "final_loss_rank0": loss_end},
+        "config": {"workload": "netlib_full: BASELINE.json configs[2], 97 instances / 1,074,147 nnz per global batch, "
+                               + ("sharded over the ranks by nnz" if head["scaling"] == "strong" and world > 1
+                                  else "one block-diagonal batch per GPU")
+                               + ", one Adam step per global batch: fwd + BCE + bwd + gradient all-reduce + Adam, fp32",
+                   "global_batch": head["global_batch"], "instances_rank0": head["instances_this_rank"],
+                   "nnz_rank0": head["nnz_this_rank"], "hip_graph": head["hip_graph"],
+                   "parallelism": f"dp{world}", "final_loss_rank0": head["final_loss_rank0"]},
     }
-    del trainer
+    if world > 1:      # the other scaling mode beside the headline
+        other = "weak" if args.scaling == "strong" else "strong"
+        out["netlib_" + other] = run_netlib(other)
+
+    # reference semantics beside the batched headline: ONE Adam step per instance (experiment.py:123-144),
+    # every instance its own HBM-resident batch; like-for-like with cpu_baseline (rank 0, single-GPU runs)
+    if world == 1 and not args.no_cpu_baseline:
+        singles = [LPBatch.from_instances([i]) for i in instances]
+        tr1 = LPTrainer(params0, lr=1e-3, use_hip_graph=use_graph, global_instances=1)
+        for b in singles:
+            tr1.step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for b in singles:
+                tr1.step(b)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        out["per_instance_steps"] = {"value": 3 * n_inst / dt1, "unit": "instances/s",
+                                     "what": "batch_size 1: one Adam step per instance, 3 epochs of the 97 instances"}
+        del tr1, singles
 
     # ---------------- roofline + synthetic throughput ------------------------------------------
     if not args.no_synthetic:
@@ -269,7 +320,10 @@ def main():
                            "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
                                        f"nnz={sb.nnz}", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": gbs_a / HBM_PEAK_GBS, "alg_bytes_per_launch": b_a, "ms_per_launch": ms_a,
-                           "traffic": load_traffic("spmm_tiled"), "kernels": kernels}
+                           "traffic": load_traffic("spmm_tiled"),
+                           "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc passes, gfx950-"
+                                             "corrected; precomputed, not measured by this run)",
+                           "kernels": kernels}
         del Hn
         # full training step on the synthetic batch
         tr = LPTrainer(params0, lr=1e-3, use_hip_graph=False, global_instances=sb.n_inst * world)
@@ -286,13 +340,46 @@ def main():
                             "ms_per_step": 1e3 * dts / args.synthetic_steps,
                             "value": sb.n_inst * world * args.synthetic_steps / dts, "unit": "instances/s",
                             "generate_s": t_gen}
+        # configs[4] as STRONG scaling: one Adam step per 2048 instances = 8 / N micro-batches of 256 per rank, gradients
+        # accumulated, one all-reduce.  The micro-batches reuse the resident synthetic batch (same work per launch;
+        # 8 distinct 256-instance batches with their tiled copies do not fit in 288 GB).
+        if sb.n_inst == 256 and 8 % world == 0:
+            from mllp_amd.trainer import allreduce_sum_
+            micro = 8 // world
+            acc = torch.zeros_like(tr.params)
+            g_ = torch.zeros_like(tr.params)
+            lg_, ls_ = torch.empty(sb.N, device="cuda"), torch.empty(1, device="cuda")
+
+            def strong_step():
+                acc.zero_()
+                for _ in range(micro):
+                    sb.loss_step(tr.params, 1.0 / 2048.0, lg_, ls_, g_)
+                    acc.add_(g_)
+                if dist_on:
+                    allreduce_sum_(acc)
+                tr.opt.step(acc)
+            strong_step()
+            barrier_sync(dist_on)
+            t0 = time.perf_counter()
+            n_strong = max(2, args.synthetic_steps // 4)
+            for _ in range(n_strong):
+                strong_step()
+            barrier_sync(dist_on)
+            dtg = max_over_ranks(time.perf_counter() - t0, dist_on)
+            out["synthetic_strong"] = {"workload": "configs[4]: global batch 2048 instances per Adam step, sharded "
+                                                   f"{256 * micro} per GPU as {micro} micro-batches of 256",
+                                       "scaling": "strong", "global_batch": 2048, "steps": n_strong,
+                                       "ms_per_step": 1e3 * dtg / n_strong, "value": 2048 * n_strong / dtg,
+                                       "unit": "instances/s"}
         del tr, sb
         torch.cuda.empty_cache()
 
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(instances)
-        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = cpu_baseline(instances, args.cpu_threads)
+        out["speedup_vs_cpu_baseline"] = {"batched_step": value / out["cpu_baseline"]["value"],
+                                          "per_instance_steps (like for like)":
+                                              out["per_instance_steps"]["value"] / out["cpu_baseline"]["value"]}
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

@@ -4,11 +4,10 @@
 // (BipartiteData.__inc__ batching offsets): done ONCE per batch, on the host, in parallel over
 // instances (they are independent blocks of the block-diagonal matrix), then uploaded.
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstring>
-#include <thread>
 
+#include "host_graph.h"
 #include "internal.h"
 
 namespace mllp {
@@ -38,49 +37,27 @@ static int upload(mllp_graph* g, const T* host, size_t count, T** dev) {
 }
 
 static void choose_tiers(mllp_graph* g) {
-    // Few rows (real Netlib, ~1M nonzeros): a sweep is latency bound, so long rows are spread over many
-    // lanes early and very long rows over several workgroups; every work item then loops <= ~4 times.
-    // Many rows (synthetic, 5e8 nonzeros): throughput bound, 16 lanes per row keep every lane busy and
-    // need no cross-wave merge.
-    const bool throughput = g->nnz >= (int64_t)32 << 20;
-    if (g->tier_wave <= 0) g->tier_wave = throughput ? 1024 : 64;
-    if (g->tier_block <= 0) g->tier_block = throughput ? 16384 : 256;
-    if (g->tier_block < g->tier_wave) g->tier_block = g->tier_wave;
-    g->chunk_nnz = 4 * g->tier_block;
+    const TierConfig c = host_choose_tiers(g->nnz, g->tier_wave, g->tier_block);
+    g->tier_wave = c.tier_wave; g->tier_block = c.tier_block; g->chunk_nnz = c.chunk_nnz;
 }
 
 static int build_tiers(mllp_graph* g, Orient& o, const int* h_ptr) {
-    std::vector<int> rg, rw, ck, sp;
-    int slots = 0;
-    for (int r = 0; r < o.n_dst; ++r) {
-        const int beg = h_ptr[r], end = h_ptr[r + 1], deg = end - beg;
-        if (deg > g->tier_block) {
-            const int nck = (deg + g->chunk_nnz - 1) / g->chunk_nnz;
-            if (nck == 1) {
-                ck.insert(ck.end(), {r, beg, end, -1});
-            } else {
-                sp.insert(sp.end(), {r, slots, nck, 0});
-                const int per = ((deg + nck - 1) / nck + 255) & ~255;   // equal shares, whole 256-nonzero passes
-                for (int c = 0; c < nck; ++c) {
-                    const int cb = std::min(beg + c * per, end), ce = std::min(cb + per, end);
-                    ck.insert(ck.end(), {r, cb, ce, slots++});   // an empty tail chunk merges as a neutral state
-                }
-            }
-        } else if (deg > g->tier_wave) rw.push_back(r);
-        else rg.push_back(r);
-    }
-    o.n_group = (int)rg.size();
+    HostTiers t;
+    TierConfig c;
+    c.tier_wave = g->tier_wave; c.tier_block = g->tier_block; c.chunk_nnz = g->chunk_nnz;
+    host_build_tiers(h_ptr, o.n_dst, c, &t);
+    o.n_group = t.n_group;
     o.tier_wave = g->tier_wave;
-    o.short_rows = o.n_dst > 0 && (double)h_ptr[o.n_dst] / o.n_dst <= 16.0;
-    o.n_wave = (int)rw.size();
-    o.n_chunk = (int)(ck.size() / 4);
-    o.n_split = (int)(sp.size() / 4);
-    o.n_slots = slots;
+    o.short_rows = t.short_rows;
+    o.n_wave = (int)t.rows_wave.size();
+    o.n_chunk = (int)(t.chunks.size() / 4);
+    o.n_split = (int)(t.split.size() / 4);
+    o.n_slots = t.n_slots;
     int rc;
     o.rows_group = nullptr;  // the group tier visits every row and skips the long ones in-kernel
-    if ((rc = upload(g, rw.data(), rw.size(), &o.rows_wave))) return rc;
-    if ((rc = upload(g, ck.data(), ck.size(), &o.chunks))) return rc;
-    if ((rc = upload(g, sp.data(), sp.size(), &o.split))) return rc;
+    if ((rc = upload(g, t.rows_wave.data(), t.rows_wave.size(), &o.rows_wave))) return rc;
+    if ((rc = upload(g, t.chunks.data(), t.chunks.size(), &o.chunks))) return rc;
+    if ((rc = upload(g, t.split.data(), t.split.size(), &o.split))) return rc;
     return MLLP_OK;
 }
 
@@ -125,73 +102,16 @@ extern "C" int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, con
                                       int32_t tier_wave, int32_t tier_block, mllp_graph_t** out) {
     if (!out) return fail(MLLP_EINVAL, "mllp_graph_create_host: out is null");
     *out = nullptr;
-    if (n_inst < 0 || (n_inst > 0 && (!inst_m || !inst_n || !indptr)))
-        return fail(MLLP_EINVAL, "mllp_graph_create_host: null instance arrays");
-    std::vector<int64_t> pm(n_inst + 1, 0), pn(n_inst + 1, 0), pe(n_inst + 1, 0), pp(n_inst + 1, 0);
-    for (int64_t k = 0; k < n_inst; ++k) {
-        if (inst_m[k] < 0 || inst_n[k] < 0) return fail(MLLP_EINVAL, "negative instance size");
-        pm[k + 1] = pm[k] + inst_m[k];
-        pn[k + 1] = pn[k] + inst_n[k];
-        pp[k + 1] = pp[k] + inst_m[k] + 1;
-        const int64_t* ip = indptr + pp[k];
-        if (ip[0] != 0) return fail(MLLP_EINVAL, "indptr block does not start at 0");
-        pe[k + 1] = pe[k] + ip[inst_m[k]];
+    HostBatch hb;
+    {
+        std::string err;
+        const int hrc = host_build_batch(n_inst, inst_m, inst_n, indptr, indices, values, &hb, &err);
+        if (hrc) return fail(hrc, err);
     }
-    int64_t M = pm[n_inst], N = pn[n_inst], nnz = pe[n_inst];
-    if (nnz >= INT32_MAX - 1 || M >= INT32_MAX - 1 || N >= INT32_MAX - 1)
-        return fail(MLLP_ERANGE, "batch exceeds int32 indexing");
-    if (nnz > 0 && (!indices || !values)) return fail(MLLP_EINVAL, "null indices/values");
-
-    std::vector<int> csr_ptr(M + 1), csr_idx(nnz), csc_ptr(N + 1), csc_idx(nnz);
-    std::vector<float> csr_val(nnz), csc_val(nnz);
-    csr_ptr[0] = 0;
-    csc_ptr[0] = 0;
-    std::atomic<int> bad{0};
-    std::atomic<int64_t> next{0};
-    auto worker = [&]() {
-        std::vector<int> cnt;
-        for (;;) {
-            int64_t k = next.fetch_add(1);
-            if (k >= n_inst) break;
-            int64_t m = inst_m[k], n = inst_n[k], e0 = pe[k];
-            const int64_t* ip = indptr + pp[k];
-            const int32_t* ix = indices + e0;
-            const double* va = values + e0;
-            cnt.assign(n + 1, 0);
-            for (int64_t r = 0; r < m; ++r) {
-                if (ip[r + 1] < ip[r]) { bad = 1; break; }
-                csr_ptr[pm[k] + r + 1] = (int)(e0 + ip[r + 1]);
-                int prev = -1;
-                for (int64_t e = ip[r]; e < ip[r + 1]; ++e) {
-                    int c = ix[e];
-                    if (c < 0 || c >= n || c <= prev) { bad = 2; break; }  // sorted, unique, in range
-                    prev = c;
-                    csr_idx[e0 + e] = (int)(pn[k] + c);
-                    csr_val[e0 + e] = (float)va[e];
-                    cnt[c + 1]++;
-                }
-            }
-            if (bad) break;
-            // counting sort by column: stable, so constraint ids ascend within each column
-            for (int64_t c = 0; c < n; ++c) cnt[c + 1] += cnt[c];
-            for (int64_t c = 0; c < n; ++c) csc_ptr[pn[k] + c + 1] = (int)(e0 + cnt[c + 1]);
-            for (int64_t r = 0; r < m; ++r)
-                for (int64_t e = ip[r]; e < ip[r + 1]; ++e) {
-                    int c = ix[e];
-                    int64_t pos = e0 + cnt[c]++;
-                    csc_idx[pos] = (int)(pm[k] + r);
-                    csc_val[pos] = (float)va[e];
-                }
-        }
-    };
-    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(n_inst, 1));
-    std::vector<std::thread> th;
-    for (unsigned i = 1; i < nt; ++i) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
-    if (bad == 1) return fail(MLLP_EINVAL, "indptr not monotone");
-    if (bad == 2) return fail(MLLP_EINVAL, "column ids must be in range, sorted and unique within a row");
+    const int64_t M = hb.M, N = hb.N, nnz = hb.nnz;
+    const std::vector<int>&csr_ptr = hb.csr_ptr, &csr_idx = hb.csr_idx, &csc_ptr = hb.csc_ptr, &csc_idx = hb.csc_idx;
+    const std::vector<float>&csr_val = hb.csr_val, &csc_val = hb.csc_val;
+    const std::vector<int64_t>&pm = hb.pm, &pn = hb.pn;
 
     mllp_graph* g = new mllp_graph();
     g->M = M; g->N = N; g->nnz = nnz; g->n_inst = n_inst;

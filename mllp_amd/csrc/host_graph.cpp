@@ -1,0 +1,137 @@
+// host_graph.cpp -- see host_graph.h.  Plain C++17, no HIP.
+#include "host_graph.h"
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "../../include/mllp_hip.h"
+
+namespace mllp {
+
+int host_build_batch(int64_t n_inst, const int64_t* inst_m, const int64_t* inst_n, const int64_t* indptr,
+                     const int32_t* indices, const double* values, HostBatch* out, std::string* err,
+                     unsigned max_threads) {
+    auto bad_arg = [&](int code, const char* msg) {
+        if (err) *err = msg;
+        return code;
+    };
+    if (!out) return bad_arg(MLLP_EINVAL, "host_build_batch: out is null");
+    if (n_inst < 0 || (n_inst > 0 && (!inst_m || !inst_n || !indptr)))
+        return bad_arg(MLLP_EINVAL, "mllp_graph_create_host: null instance arrays");
+    std::vector<int64_t> pm(n_inst + 1, 0), pn(n_inst + 1, 0), pe(n_inst + 1, 0), pp(n_inst + 1, 0);
+    for (int64_t k = 0; k < n_inst; ++k) {
+        if (inst_m[k] < 0 || inst_n[k] < 0) return bad_arg(MLLP_EINVAL, "negative instance size");
+        pm[k + 1] = pm[k] + inst_m[k];
+        pn[k + 1] = pn[k] + inst_n[k];
+        pp[k + 1] = pp[k] + inst_m[k] + 1;
+        const int64_t* ip = indptr + pp[k];
+        if (ip[0] != 0) return bad_arg(MLLP_EINVAL, "indptr block does not start at 0");
+        if (ip[inst_m[k]] < 0) return bad_arg(MLLP_EINVAL, "indptr not monotone");
+        pe[k + 1] = pe[k] + ip[inst_m[k]];
+    }
+    const int64_t M = pm[n_inst], N = pn[n_inst], nnz = pe[n_inst];
+    if (nnz >= INT32_MAX - 1 || M >= INT32_MAX - 1 || N >= INT32_MAX - 1)
+        return bad_arg(MLLP_ERANGE, "batch exceeds int32 indexing");
+    if (nnz > 0 && (!indices || !values)) return bad_arg(MLLP_EINVAL, "null indices/values");
+
+    HostBatch& b = *out;
+    b.M = M; b.N = N; b.nnz = nnz; b.n_inst = n_inst;
+    b.csr_ptr.assign(M + 1, 0); b.csr_idx.assign(nnz, 0); b.csr_val.assign(nnz, 0.0f);
+    b.csc_ptr.assign(N + 1, 0); b.csc_idx.assign(nnz, 0); b.csc_val.assign(nnz, 0.0f);
+    // instances are independent blocks: every worker writes only the index ranges of the instances it draws
+    std::atomic<int> bad{0};
+    std::atomic<int64_t> next{0};
+    auto worker = [&]() {
+        std::vector<int> cnt;
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_inst || bad.load()) break;
+            const int64_t m = inst_m[k], n = inst_n[k], e0 = pe[k], e1 = pe[k + 1];
+            const int64_t* ip = indptr + pp[k];
+            const int32_t* ix = indices + e0;
+            const double* va = values + e0;
+            cnt.assign(n + 1, 0);
+            bool ok = true;
+            for (int64_t r = 0; r < m && ok; ++r) {
+                if (ip[r + 1] < ip[r] || ip[r + 1] > e1 - e0) { bad = 1; ok = false; break; }
+                b.csr_ptr[pm[k] + r + 1] = (int)(e0 + ip[r + 1]);
+                int prev = -1;
+                for (int64_t e = ip[r]; e < ip[r + 1]; ++e) {
+                    const int c = ix[e];
+                    if (c < 0 || c >= n || c <= prev) { bad = 2; ok = false; break; }  // sorted, unique, in range
+                    prev = c;
+                    b.csr_idx[e0 + e] = (int)(pn[k] + c);
+                    b.csr_val[e0 + e] = (float)va[e];
+                    cnt[c + 1]++;
+                }
+            }
+            if (!ok) break;
+            // counting sort by column: stable, so constraint ids ascend within each column
+            for (int64_t c = 0; c < n; ++c) cnt[c + 1] += cnt[c];
+            for (int64_t c = 0; c < n; ++c) b.csc_ptr[pn[k] + c + 1] = (int)(e0 + cnt[c + 1]);
+            for (int64_t r = 0; r < m; ++r)
+                for (int64_t e = ip[r]; e < ip[r + 1]; ++e) {
+                    const int c = ix[e];
+                    const int64_t pos = e0 + cnt[c]++;
+                    b.csc_idx[pos] = (int)(pm[k] + r);
+                    b.csc_val[pos] = (float)va[e];
+                }
+        }
+    };
+    unsigned nt = max_threads ? max_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(n_inst, 1));
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    if (bad == 1) return bad_arg(MLLP_EINVAL, "indptr not monotone");
+    if (bad == 2) return bad_arg(MLLP_EINVAL, "column ids must be in range, sorted and unique within a row");
+    b.pm = std::move(pm);
+    b.pn = std::move(pn);
+    return MLLP_OK;
+}
+
+TierConfig host_choose_tiers(int64_t nnz, int tier_wave, int tier_block) {
+    // Few rows (real Netlib, ~1M nonzeros): a sweep is latency bound, so long rows are spread over many
+    // lanes early and very long rows over several workgroups; every work item then loops <= ~4 times.
+    // Many rows (synthetic, 5e8 nonzeros): throughput bound, 16 lanes per row keep every lane busy and
+    // need no cross-wave merge.
+    const bool throughput = nnz >= (int64_t)32 << 20;
+    TierConfig c;
+    c.tier_wave = tier_wave > 0 ? tier_wave : (throughput ? 1024 : 64);
+    c.tier_block = tier_block > 0 ? tier_block : (throughput ? 16384 : 256);
+    if (c.tier_block < c.tier_wave) c.tier_block = c.tier_wave;
+    c.chunk_nnz = 4 * c.tier_block;
+    return c;
+}
+
+void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTiers* out) {
+    HostTiers& t = *out;
+    t = HostTiers();
+    int slots = 0;
+    for (int r = 0; r < n_dst; ++r) {
+        const int beg = ptr[r], end = ptr[r + 1], deg = end - beg;
+        if (deg > cfg.tier_block) {
+            const int nck = (deg + cfg.chunk_nnz - 1) / cfg.chunk_nnz;
+            if (nck == 1) {
+                t.chunks.insert(t.chunks.end(), {r, beg, end, -1});
+            } else {
+                t.split.insert(t.split.end(), {r, slots, nck, 0});
+                const int per = ((deg + nck - 1) / nck + 255) & ~255;   // equal shares, whole 256-nonzero passes
+                for (int c = 0; c < nck; ++c) {
+                    const int cb = std::min(beg + c * per, end), ce = std::min(cb + per, end);
+                    t.chunks.insert(t.chunks.end(), {r, cb, ce, slots++});   // an empty tail chunk merges as a neutral state
+                }
+            }
+        } else if (deg > cfg.tier_wave) {
+            t.rows_wave.push_back(r);
+        } else {
+            t.n_group++;
+        }
+    }
+    t.n_slots = slots;
+    t.short_rows = n_dst > 0 && (double)ptr[n_dst] / n_dst <= 16.0;
+}
+
+}  // namespace mllp

@@ -1,0 +1,166 @@
+// host_graph_test.cpp -- sanitizer driver for host_graph.cpp (built by `make host-sanitize` with
+// -fsanitize=address,undefined and with -fsanitize=thread; run by tests/test_host_sanitize.py).
+// Random ragged batches (empty rows, empty columns, empty instances, one very long row) through the parallel
+// build with 8 threads; the result is checked against a serial transposition, the row tiers against the rows.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <random>
+
+#include "../../include/mllp_hip.h"
+#include "host_graph.h"
+
+using namespace mllp;
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            std::exit(1);                                               \
+        }                                                               \
+    } while (0)
+
+struct Raw {
+    std::vector<int64_t> m, n, indptr;
+    std::vector<int32_t> idx;
+    std::vector<double> val;
+};
+
+static Raw random_batch(std::mt19937& rng, int n_inst, int long_row) {
+    Raw r;
+    for (int k = 0; k < n_inst; ++k) {
+        const int m = (k % 7 == 3) ? 0 : 1 + (int)(rng() % 60);
+        const int n = (k % 11 == 5) ? 0 : 1 + (int)(rng() % 90);
+        r.m.push_back(m);
+        r.n.push_back(n);
+        int64_t e = 0;
+        r.indptr.push_back(0);
+        for (int row = 0; row < m; ++row) {
+            int deg = n == 0 ? 0 : (int)(rng() % 5);
+            if (rng() % 4 == 0) deg = 0;
+            if (k == 1 && row == 0) deg = std::min(n, long_row);
+            deg = std::min(deg, n);
+            std::vector<int> cols(n);
+            for (int c = 0; c < n; ++c) cols[c] = c;
+            for (int c = 0; c < deg; ++c) std::swap(cols[c], cols[c + rng() % (n - c)]);
+            std::sort(cols.begin(), cols.begin() + deg);
+            for (int c = 0; c < deg; ++c) {
+                r.idx.push_back(cols[c]);
+                r.val.push_back((double)(int)(rng() % 2001 - 1000) / 1000.0);
+            }
+            e += deg;
+            r.indptr.push_back(e);
+        }
+    }
+    return r;
+}
+
+static void check_batch(const Raw& r, const HostBatch& b) {
+    const int64_t n_inst = (int64_t)r.m.size();
+    CHECK(b.n_inst == n_inst && (int64_t)b.pm.size() == n_inst + 1);
+    // serial reference: dense-free transposition by (column, row) sort
+    std::vector<std::vector<std::pair<int, float>>> cols(b.N);
+    int64_t e = 0, pp = 0;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        for (int64_t row = 0; row < r.m[k]; ++row) {
+            const int64_t gr = b.pm[k] + row;
+            CHECK(b.csr_ptr[gr] == e);
+            for (int64_t q = r.indptr[pp + row]; q < r.indptr[pp + row + 1]; ++q, ++e) {
+                const int64_t idx_pos = e;
+                CHECK(b.csr_idx[idx_pos] == (int)(b.pn[k] + r.idx[idx_pos]));
+                CHECK(b.csr_val[idx_pos] == (float)r.val[idx_pos]);
+                cols[b.pn[k] + r.idx[idx_pos]].push_back({(int)gr, (float)r.val[idx_pos]});
+            }
+        }
+        pp += r.m[k] + 1;
+    }
+    CHECK(e == b.nnz && b.csr_ptr[b.M] == b.nnz && b.csc_ptr[b.N] == b.nnz && b.csc_ptr[0] == 0);
+    for (int64_t c = 0; c < b.N; ++c) {
+        CHECK(b.csc_ptr[c + 1] - b.csc_ptr[c] == (int)cols[c].size());
+        for (size_t j = 0; j < cols[c].size(); ++j) {
+            CHECK(b.csc_idx[b.csc_ptr[c] + j] == cols[c][j].first);      // constraint ids ascending
+            CHECK(b.csc_val[b.csc_ptr[c] + j] == cols[c][j].second);
+        }
+    }
+}
+
+static void check_tiers(const int* ptr, int n_dst, const TierConfig& c) {
+    HostTiers t;
+    host_build_tiers(ptr, n_dst, c, &t);
+    std::vector<int> covered(n_dst, 0);
+    std::vector<int> nnz_in_chunks(n_dst, 0);
+    for (int r : t.rows_wave) {
+        CHECK(r >= 0 && r < n_dst);
+        const int deg = ptr[r + 1] - ptr[r];
+        CHECK(deg > c.tier_wave && deg <= c.tier_block);
+        covered[r]++;
+    }
+    CHECK(t.chunks.size() % 4 == 0 && t.split.size() % 4 == 0);
+    int slots_seen = 0;
+    for (size_t i = 0; i < t.chunks.size(); i += 4) {
+        const int r = t.chunks[i], beg = t.chunks[i + 1], end = t.chunks[i + 2], slot = t.chunks[i + 3];
+        CHECK(r >= 0 && r < n_dst && beg >= ptr[r] && end <= ptr[r + 1] && beg <= end);
+        CHECK(end - beg <= c.chunk_nnz + 256);
+        nnz_in_chunks[r] += end - beg;
+        if (slot < 0) covered[r]++;
+        else { CHECK(slot == slots_seen); slots_seen++; }
+    }
+    CHECK(slots_seen == t.n_slots);
+    int slot0 = 0;
+    for (size_t i = 0; i < t.split.size(); i += 4) {
+        const int r = t.split[i];
+        CHECK(t.split[i + 1] == slot0 && t.split[i + 2] >= 2);
+        slot0 += t.split[i + 2];
+        covered[r]++;
+    }
+    CHECK(slot0 == t.n_slots);
+    int n_group = 0;
+    for (int r = 0; r < n_dst; ++r) {
+        const int deg = ptr[r + 1] - ptr[r];
+        if (deg <= c.tier_wave) { CHECK(covered[r] == 0); n_group++; }
+        else CHECK(covered[r] == 1);
+        if (deg > c.tier_block) CHECK(nnz_in_chunks[r] == deg);
+    }
+    CHECK(n_group == t.n_group);
+}
+
+int main() {
+    std::mt19937 rng(12345);
+    for (int round = 0; round < 6; ++round) {
+        const int n_inst = round == 0 ? 1 : 5 + 9 * round;
+        Raw r = random_batch(rng, n_inst, 70);
+        HostBatch b;
+        std::string err;
+        const int rc = host_build_batch(n_inst, r.m.data(), r.n.data(), r.indptr.data(), r.idx.data(), r.val.data(),
+                                        &b, &err, 8);
+        CHECK(rc == MLLP_OK);
+        check_batch(r, b);
+        for (int tw : {1, 4, 64})
+            for (int tb : {2, 16, 256}) {
+                TierConfig c = host_choose_tiers(b.nnz, tw, tb);
+                CHECK(c.tier_block >= c.tier_wave && c.chunk_nnz == 4 * c.tier_block);
+                check_tiers(b.csr_ptr.data(), (int)b.M, c);
+                check_tiers(b.csc_ptr.data(), (int)b.N, c);
+            }
+    }
+    {   // empty batch and argument errors
+        HostBatch b;
+        std::string err;
+        CHECK(host_build_batch(0, nullptr, nullptr, nullptr, nullptr, nullptr, &b, &err) == MLLP_OK && b.nnz == 0);
+        const int64_t m1[1] = {2}, n1[1] = {3};
+        const int64_t ip_ok[3] = {0, 2, 3};
+        const int32_t ix_unsorted[3] = {2, 1, 0}, ix_range[3] = {0, 3, 1}, ix_ok[3] = {0, 2, 1};
+        const double v[3] = {1.0, 2.0, 3.0};
+        CHECK(host_build_batch(1, m1, n1, ip_ok, ix_unsorted, v, &b, &err, 2) == MLLP_EINVAL);
+        CHECK(host_build_batch(1, m1, n1, ip_ok, ix_range, v, &b, &err, 2) == MLLP_EINVAL);
+        CHECK(host_build_batch(1, m1, n1, ip_ok, ix_ok, v, &b, &err, 2) == MLLP_OK);
+        const int64_t ip_bad[3] = {0, 2, 1}, ip_off[3] = {1, 2, 3};
+        CHECK(host_build_batch(1, m1, n1, ip_bad, ix_ok, v, &b, &err, 2) == MLLP_EINVAL);
+        CHECK(host_build_batch(1, m1, n1, ip_off, ix_ok, v, &b, &err, 2) == MLLP_EINVAL);
+        const int64_t neg[1] = {-1};
+        CHECK(host_build_batch(1, neg, n1, ip_ok, ix_ok, v, &b, &err, 2) == MLLP_EINVAL);
+        CHECK(host_choose_tiers(100, 0, 0).tier_wave == 64 && host_choose_tiers((int64_t)40 << 20, 0, 0).tier_wave == 1024);
+    }
+    std::puts("host_graph sanitizer driver: ok");
+    return 0;
+}

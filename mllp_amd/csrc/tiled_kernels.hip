@@ -12,12 +12,11 @@
 //             belongs to.  Same 8 bytes per nonzero as CSR (+ 6 bytes per (row, block)), streamed once, coalesced.
 //   workgroup 1024 threads = one row tile = one CU (150 KB of LDS).  For each column block the tile touches:
 //               LDS  <-  64 KB of H (CB x 64 B)  +  the block's entry segment (<= 48 KB per window)  +  offsets/perm,
-//             all prefetched into REGISTERS while the previous block is computed (issue early, write late).
+//             prefetched into REGISTERS while the previous block is computed (issue early, write late).
 //             Then every QUAD of lanes takes one sorted position: the 16 quads of a wave therefore walk rows of
-//             (nearly) EQUAL length in lockstep -- the first version (quad = fixed rows, Poisson lengths) ran the
+//             (nearly) EQUAL length in lockstep -- a first version (quad = fixed rows, Poisson lengths) ran the
 //             SIMD and the LDS at 59 % efficiency.  A quad loads the row's accumulator from LDS, walks the row
-//             (entry: ds_read_b64, source row piece: ds_read_b128, 4 FMAs per lane), stores it back.  Waves take
-//             bundles in snake order (w and 31 - w) so that every wave gets the same amount of work.
+//             (entry: ds_read_b64, source row piece: ds_read_b128, 4 FMAs per lane), stores it back.
 //   traffic   per tile: the entry stream once from HBM + (blocks touched) x 64 KB of H from L2 as wide coalesced
 //             loads: one L2 request per 128 B instead of one per nonzero; the output tile is written once.
 #include <cstdlib>
@@ -32,9 +31,7 @@ constexpr int T_WAVES = T_THREADS / 64;
 constexpr int T_R = 512;                   // rows per tile: 32 bundles of 16 sorted positions
 constexpr int T_BUNDLES = T_R / 16;
 constexpr int T_CB = 1024;                 // source nodes per column block (64 KB of fp32 x 16)
-constexpr int T_EPT = 6;                   // entries prefetched per thread
-constexpr int T_ECAP = T_EPT * T_THREADS;  // 6144 entries (48 KB) of a (tile, block) segment per window
-constexpr int T_XPT = (T_CB * 4) / T_THREADS;   // float4 of H per thread
+constexpr int T_ECAP = 6 * T_THREADS;      // 6144 entries (48 KB) of a (tile, block) segment per window
 constexpr int T_MAXB = 255;                // column blocks one row tile may touch (checked at attach)
 
 // sum over the 4 lanes of a quad (every lane gets the total)
@@ -63,168 +60,9 @@ struct TiledDev {
     int n_tiles, n_dst, n_src;
 };
 
-// ABL: ablation mask for timing-only builds (results wrong when != 0): 1 = no H loads, 2 = no entry loads,
-// 4 = no walk, 8 = no LDS writes of H / entries, 16 = instead of the result, row `tile` of Y receives the cycles
-// (s_memtime, summed over the 16 waves) spent in {barrier 1, vmcnt wait + ds_write, barrier 2, prefetch issue,
-// walk, whole kernel}
-template <int ABL>
-__global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 128 VGPRs: no spills
-void spmm_tiled_kernel(TiledDev t, const float* __restrict__ X,
-                                                               float* __restrict__ Y) {
-    __shared__ float4 Xs[T_CB * 4];     // 64 KB  staged column block of H
-    __shared__ int2 Es[T_ECAP];         // 48 KB  entry segment (window)
-    __shared__ float4 Ya[T_R * 4];      // 32 KB  accumulators of the row tile
-    __shared__ int Ps[T_R + 16];        // offsets of the sorted positions inside the segment
-    __shared__ int Pm[T_R];             // row of each sorted position
-    __shared__ int Sg[T_MAXB + 1];      // segment start of every block of this tile (no dependent global loads later)
-    __shared__ int Bk[T_MAXB];          // column-block id of every block of this tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int quad = lane >> 2, part = lane & 3;
-    const int tile = xcd_tile(blockIdx.x, t.n_tiles);
-    const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
-
-    for (int i = tid; i < T_R * 4; i += T_THREADS) Ya[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid <= tb1 - tb0) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * T_R];
-    if (tid < tb1 - tb0) Bk[tid] = t.blk_id[tb0 + tid];
-    __syncthreads();
-
-    // ---- register prefetch of a (tile, block): H piece, entries of the first window, offsets, perm.
-    //      TWO register sets (A, B): the loads of block b+2 are issued while block b is computed.  Loads are
-    //      never predicated (addresses are clamped instead) so that the compiler can use counted vmcnt waits,
-    //      and half of the waves burst their loads before the walk, the other half after it.
-    //      (Macros, not lambdas over a struct reference: that form was demoted to scratch memory.)
-#define T_LDX(S, K)                                                                                         \
-    px##S##K = (ABL & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : src_[min(tid + K * T_THREADS, c4_ - 1)];
-#define T_LDE(S, K)                                                                                         \
-    pe##S##K = (ABL & 2) ? make_int2(0, 0) : t.ent[seg0##S + min(tid + K * T_THREADS, max(len##S - 1, 0))];
-#define T_PREFETCH(S, TB)                                                                                   \
-    {                                                                                                       \
-        const int tbx_ = (TB);                                                                              \
-        const int c0_ = Bk[tbx_ - tb0] * T_CB;                                                              \
-        const int c4_ = min(T_CB, t.n_src - c0_) * 4;                                                       \
-        const float4* src_ = reinterpret_cast<const float4*>(X + (size_t)c0_ * 16);                        \
-        T_LDX(S, 0) T_LDX(S, 1) T_LDX(S, 2) T_LDX(S, 3)                                                     \
-        seg0##S = Sg[tbx_ - tb0];                                                                           \
-        len##S = Sg[tbx_ - tb0 + 1] - seg0##S;                                                              \
-        pp##S = t.ptr2[(size_t)tbx_ * T_R + min(tid, T_R - 1)] - seg0##S;                                   \
-        pm##S = t.perm[(size_t)tbx_ * T_R + min(tid, T_R - 1)];                                             \
-        T_LDE(S, 0) T_LDE(S, 1) T_LDE(S, 2) T_LDE(S, 3) T_LDE(S, 4) T_LDE(S, 5)                             \
-    }
-
-    // one block: registers -> LDS, refill the register set with block tb + 2, walk
-#define T_TICK(K)                                                                                           \
-    if (ABL & 16) {                                                                                         \
-        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();                                       \
-        cyc[K] += now_ - last_;                                                                             \
-        last_ = now_;                                                                                       \
-    }
-#define T_DO_BLOCK(S, TB)                                                                                   \
-    {                                                                                                       \
-        const int tbc_ = (TB);                                                                              \
-        T_TICK(4)                                                                                           \
-        __syncthreads(); /* every wave is done with the previous block's LDS image */                      \
-        T_TICK(0)                                                                                           \
-        Xs[tid] = px##S##0; Xs[tid + T_THREADS] = px##S##1;                                                 \
-        Xs[tid + 2 * T_THREADS] = px##S##2; Xs[tid + 3 * T_THREADS] = px##S##3;                             \
-        Es[tid] = pe##S##0; Es[tid + T_THREADS] = pe##S##1; Es[tid + 2 * T_THREADS] = pe##S##2;             \
-        Es[tid + 3 * T_THREADS] = pe##S##3; Es[tid + 4 * T_THREADS] = pe##S##4;                             \
-        Es[tid + 5 * T_THREADS] = pe##S##5;                                                                 \
-        if (tid < T_R) {                                                                                    \
-            Ps[tid] = pp##S;                                                                                \
-            Pm[tid] = pm##S;                                                                                \
-        }                                                                                                   \
-        if (tid == 0) Ps[T_R] = len##S;                                                                     \
-        const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
-        T_TICK(1)                                                                                           \
-        __syncthreads();                                                                                    \
-        T_TICK(2)                                                                                           \
-        const int tb_next = min(tbc_ + 2, tb1 - 1); /* the tail refetches the last block */                \
-        if (early) T_PREFETCH(S, tb_next)                                                                   \
-        T_TICK(3)                                                                                           \
-        walk(cur_seg0, cur_len);                                                                            \
-        T_TICK(4)                                                                                           \
-        if (!early) T_PREFETCH(S, tb_next)                                                                  \
-        T_TICK(3)                                                                                           \
-    }
-
-    auto walk = [&](int cur_seg0, int cur_len) {
-        for (int w0 = 0; w0 < ((ABL & 4) ? 0 : cur_len); w0 += T_ECAP) {
-            if (w0 > 0) {                      // rare: segment longer than one window -> restage synchronously
-                __syncthreads();
-                for (int i = tid; i < min(T_ECAP, cur_len - w0); i += T_THREADS) Es[i] = t.ent[cur_seg0 + w0 + i];
-                __syncthreads();
-            }
-            const int w1 = w0 + T_ECAP;
-#pragma unroll
-            for (int pass = 0; pass < T_BUNDLES / T_WAVES; ++pass) {
-                // snake order over the length-sorted bundles: equal work per wave
-                const int bundle = (pass & 1) ? (pass + 1) * T_WAVES - 1 - wave : pass * T_WAVES + wave;
-                const int k = bundle * 16 + quad;
-                const int s = max(Ps[k], w0), e = min(Ps[k + 1], w1);
-                if (s < e) {
-                    const int rl = Pm[k];
-                    float4 a = Ya[rl * 4 + part];
-                    int p = s - w0;
-                    const int pe_ = e - w0;
-                    for (; p + 1 < pe_; p += 2) {
-                        const int2 e0 = Es[p], e1 = Es[p + 1];
-                        const float4 x0 = Xs[(e0.x >> 4) + part], x1 = Xs[(e1.x >> 4) + part];
-                        fma4(__int_as_float(e0.y), x0, a);
-                        fma4(__int_as_float(e1.y), x1, a);
-                    }
-                    if (p < pe_) {
-                        const int2 e0 = Es[p];
-                        fma4(__int_as_float(e0.y), Xs[(e0.x >> 4) + part], a);
-                    }
-                    Ya[rl * 4 + part] = a;
-                }
-            }
-        }
-    };
-    static_assert(T_XPT == 4 && T_EPT == 6, "the prefetch macros are written for 4 + 6 registers per set");
-    float4 pxA0, pxA1, pxA2, pxA3, pxB0, pxB1, pxB2, pxB3;
-    int2 peA0, peA1, peA2, peA3, peA4, peA5, peB0, peB1, peB2, peB3, peB4, peB5;
-    int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
-    const bool early = wave < T_WAVES / 2;   // half of the waves burst their loads before the walk, half after
-    unsigned cyc[5] = {0u, 0u, 0u, 0u, 0u};
-    const unsigned start_ = (ABL & 16) ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
-    unsigned last_ = start_;
-    if (tb0 < tb1) {
-        T_PREFETCH(A, tb0)
-        T_PREFETCH(B, min(tb0 + 1, tb1 - 1))
-    }
-    for (int tb = tb0; tb < tb1; tb += 2) {
-        T_DO_BLOCK(A, tb)
-        if (tb + 1 < tb1) T_DO_BLOCK(B, tb + 1)
-    }
-#undef T_LDX
-#undef T_LDE
-#undef T_PREFETCH
-#undef T_DO_BLOCK
-#undef T_TICK
-    __syncthreads();
-    if (ABL & 16) {      // timing build: per-phase cycles of this workgroup instead of the result
-        const unsigned total_ = (unsigned)__builtin_amdgcn_s_memtime() - start_;
-        int* acc = reinterpret_cast<int*>(Ps);
-        if (tid < 8) acc[tid] = 0;
-        __syncthreads();
-        if (lane == 0) {
-            for (int k = 0; k < 5; ++k) atomicAdd(&acc[k], (int)cyc[k]);
-            atomicAdd(&acc[5], (int)total_);
-        }
-        __syncthreads();
-        if (tid < 8 && tile < t.n_dst) Y[(size_t)tile * 16 + tid] = (float)acc[tid];
-        return;
-    }
-    const int row0 = tile * T_R;
-    const int n4 = min(T_R, t.n_dst - row0) * 4;
-    float4* dst = reinterpret_cast<float4*>(Y + (size_t)row0 * 16);
-    for (int i = tid; i < n4; i += T_THREADS) dst[i] = Ya[i];
-}
-
 // =================================================================================================
-// Wave-specialised SpMM (the shipped one).  The cycle counters of the version above (tools/phase_cycles.py)
-// showed every wave blocked 21 % of its time while ISSUING its prefetch (the CU's vector-memory path takes
+// Wave-specialised SpMM.  Cycle counters of a first version in which all 16 waves loaded and walked
+// (profiles/README.md) showed every wave blocked 21 % of its time while ISSUING its prefetch (the CU's vector-memory path takes
 // 64 B/clk and all 16 waves burst 110 KB per block at once), 30 % in barriers / waiting for loads, and a walk
 // that costs 15 VALU instructions per nonzero.  Here, same geometry (512 rows x 1024 columns):
 //   waves 12..15  ENTRY LOADERS: entries, offsets and perm stream from HBM into two register sets (block b+1
@@ -1406,47 +1244,32 @@ int launch_bwddst1_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w,
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwddst1_tiled");
 }
 
-// timing-only ablation switch (MLLP_TILED_ABLATION environment variable; 0 in production)
+// The product library has exactly one SpMM path and reads no environment variables.  `make timing` builds
+// libmllp_hip_timing.so with -DMLLP_TIMING_BUILD: the same kernel with its timing-only instantiations (results are
+// WRONG there when the mask is not 0: 4 = no walk, 16 = cycle counters instead of Y), selected by MLLP_TILED_ABLATION
+// and used only by tools/phase_cycles.py.
+#ifdef MLLP_TIMING_BUILD
 static int g_tiled_ablation = [] {
     const char* e = getenv("MLLP_TILED_ABLATION");
     return e ? atoi(e) : 0;
 }();
-
-// MLLP_TILED_SPMM=v1 selects the previous (all waves load and walk) kernel for A/B timing
-static int g_tiled_ws = [] {
-    const char* e = getenv("MLLP_TILED_SPMM");
-    return (e && e[0] == 'v' && e[1] == '1') ? 0 : 1;
-}();
+#endif
 
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s) {
     if (tl.n_tiles == 0) return MLLP_OK;
-    TiledDev d;
-    d.tile_blk = tl.tile_blk; d.blk_id = tl.blk_id; d.ptr2 = tl.ptr2; d.perm = tl.perm;
-    d.ent = reinterpret_cast<const int2*>(tl.ent);
-    d.n_tiles = tl.n_tiles; d.n_dst = n_dst; d.n_src = n_src;
-    if (g_tiled_ws) {
-        switch (g_tiled_ablation) {
-            case 0: hipLaunchKernelGGL(spmm_tiled_ws_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-            case 4: hipLaunchKernelGGL(spmm_tiled_ws_kernel<4>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-            case 16: hipLaunchKernelGGL(spmm_tiled_ws_kernel<16>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-            default: return fail(MLLP_EINVAL, "unknown ablation mask");
-        }
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled_ws");
-    }
+    const TiledDev d = tiled_dev(tl, n_dst, n_src);
+#ifdef MLLP_TIMING_BUILD
     switch (g_tiled_ablation) {
-        case 0: hipLaunchKernelGGL(spmm_tiled_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 1: hipLaunchKernelGGL(spmm_tiled_kernel<1>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 2: hipLaunchKernelGGL(spmm_tiled_kernel<2>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 3: hipLaunchKernelGGL(spmm_tiled_kernel<3>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 4: hipLaunchKernelGGL(spmm_tiled_kernel<4>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 7: hipLaunchKernelGGL(spmm_tiled_kernel<7>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 16: hipLaunchKernelGGL(spmm_tiled_kernel<16>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
-        case 12: hipLaunchKernelGGL(spmm_tiled_kernel<12>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+        case 0: hipLaunchKernelGGL(spmm_tiled_ws_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+        case 4: hipLaunchKernelGGL(spmm_tiled_ws_kernel<4>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
+        case 16: hipLaunchKernelGGL(spmm_tiled_ws_kernel<16>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y); break;
         default: return fail(MLLP_EINVAL, "unknown ablation mask");
     }
+#else
+    hipLaunchKernelGGL(spmm_tiled_ws_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y);
+#endif
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled");
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled_ws");
 }
 
 int tiled_max_blocks_per_tile() { return T_MAXB; }

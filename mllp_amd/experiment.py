@@ -41,13 +41,78 @@ def _dist_setup():
     return 0, 1
 
 
+def plan_batches(instances, batch_size, rank, world):
+    """Groups of `batch_size` consecutive instances (0 = the whole dataset); with world > 1 every group is sharded
+    over the ranks by nnz (trainer.shard_instances).  Returns [(global ids owned by this rank, global group size)]."""
+    from .trainer import shard_instances
+    bs = int(batch_size)
+    if bs <= 0:
+        bs = len(instances)
+    plan = []
+    for i in range(0, len(instances), bs):
+        grp = list(range(i, min(i + bs, len(instances))))
+        mine = grp if world == 1 else [grp[j] for j in shard_instances([instances[k].nnz for k in grp], world)[rank]]
+        plan.append((mine, len(grp)))
+    return plan
+
+
+def run_epochs(cfg, instances, train_dict, trainer, batches, rank, world, device, start_epoch=0, out=print,
+               save_all=None):
+    """The epoch loop of reference linear_program_experiment.py:120-157 over prebuilt batches, for any trainer
+    with `step(batch) -> (loss, logits)`, `step_empty()` and `metrics_of(batch) -> [n, 2]` (correct_num, f1).
+
+    `batches` = [(global instance ids of THIS rank, batch or None, global instance count of the group)].
+    With world > 1 the per-instance metrics of every rank are summed into one dense [n_instances, 2] tensor
+    (each instance is owned by exactly one rank), so rank 0 prints and logs the complete epoch; the other
+    ranks print nothing and write no files."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+    log_every = max(int(cfg.get_default("log_every")), 1)
+    save_every = int(cfg.get_default("save_every"))
+    for epoch in range(start_epoch, cfg.train_iter):                                # reference :120
+        obj_sum = torch.zeros(1, device=device)
+        logging = epoch % log_every == 0
+        table = torch.zeros(len(instances), 2, device=device) if logging else None
+        for mine, b, gcount in batches:
+            if b is None:      # a rank without instances in this batch still joins the all-reduce
+                trainer.step_empty()
+                continue
+            trainer.global_instances = gcount
+            loss, _ = trainer.step(b)                                               # reference :124-144
+            obj_sum += loss.to(device) * gcount     # loss is the batch mean over gcount instances (this rank's share)
+            if logging:
+                table[torch.as_tensor(mine, device=device)] = trainer.metrics_of(b).to(device)
+        if dist is not None:
+            dist.all_reduce(obj_sum)
+            if logging:
+                dist.all_reduce(table)
+        obj = float(obj_sum[0]) / len(instances)
+        if logging:
+            met = table.cpu().numpy()
+            for gi, inst in enumerate(instances):      # groups are consecutive id ranges: this is the dataset order
+                correct_num, f1 = float(met[gi, 0]), float(met[gi, 1])              # reference :146-153
+                if rank == 0:
+                    out("%8d, %8d, %8d, %5f" % (correct_num, inst.m, inst.n, f1))
+                train_dict[inst.name].append(correct_num)
+        train_dict["obj"].append(obj)                  # plain float: the reference's numpy.float32 breaks json.dump
+        if rank == 0:
+            with open("train_log.json", "w") as json_file:                          # reference :155-156
+                json.dump(train_dict, json_file)
+            out(f"epoch {epoch}, obj={obj}")                                        # reference :157
+        if save_all is not None and save_every and (epoch + 1) % save_every == 0:
+            save_all(epoch)
+    return train_dict
+
+
 def train_method(cfg, method_name, train_dataset, train_dict, out=print):
     from .graph import LPBatch
-    from .trainer import LPTrainer, shard_instances
+    from .trainer import LPTrainer
     rank, world = _dist_setup()
     model_path = f"linear_program_{cfg.train_data_type}_{method_name}.pt"
     ckpt_path = f"linear_program_{cfg.train_data_type}_{method_name}.ckpt"
-    out(f"Training the model weights for {method_name}...")
+    if rank == 0:
+        out(f"Training the model weights for {method_name}...")
     device = torch.device(cfg.get_default("device"))
     if device.type != "cuda" or not torch.cuda.is_available():
         raise RuntimeError("this build runs the learned-LP path on MI355X through HIP only (device: 'cuda'); "
@@ -59,70 +124,43 @@ def train_method(cfg, method_name, train_dataset, train_dict, out=print):
         dist.broadcast(flat0, src=0)
         model.load_flat(flat0)
     instances = [LPInstance.from_reference_tuple(t) for t in train_dataset]
-    bs = int(cfg.get_default("batch_size"))
-    if bs <= 0:
-        bs = len(instances)
-    groups = [list(range(i, min(i + bs, len(instances)))) for i in range(0, len(instances), bs)]
-    batches = []                                       # (global instance ids of this rank, LPBatch or None, global count)
-    for grp in groups:
-        mine = grp if world == 1 else [grp[j] for j in shard_instances([instances[i].nnz for i in grp], world)[rank]]
-        b = LPBatch.from_instances([instances[i] for i in mine]) if mine else None
-        batches.append((mine, b, len(grp)))
+    batches = [(mine, LPBatch.from_instances([instances[i] for i in mine]) if mine else None, gcount)
+               for mine, gcount in plan_batches(instances, cfg.get_default("batch_size"), rank, world)]
     trainer = LPTrainer(model.flat_parameters().detach(), lr=cfg.train_lr,
                         use_hip_graph=cfg.get_default("use_hip_graph"), with_metrics=True,
                         tiled_copies=cfg.get_default("tiled_copies"))
     start_epoch = 0
     if cfg.get_default("resume") and os.path.exists(ckpt_path):
-        ck = torch.load(ckpt_path, map_location=device, weights_only=True)
-        trainer.params.copy_(ck["params"])
-        trainer.opt.load_state_dict(ck["opt"])
-        start_epoch = int(ck["epoch"]) + 1
-        train_dict.update({k: list(v) for k, v in json.loads(ck["train_dict"]).items()})
-        out(f"resumed from {ckpt_path} at epoch {start_epoch}")
-    log_every = max(int(cfg.get_default("log_every")), 1)
-    save_every = int(cfg.get_default("save_every"))
+        start_epoch = load_checkpoint(ckpt_path, trainer, train_dict, device)
+        if rank == 0:
+            out(f"resumed from {ckpt_path} at epoch {start_epoch}")
 
     def save_all(epoch):
         if rank != 0:
             return
         model.load_flat(trainer.params)
         torch.save(model.state_dict(), model_path)                                   # reference :176
-        torch.save({"params": trainer.params, "opt": trainer.opt.state_dict(), "epoch": epoch,
-                    "train_dict": json.dumps(train_dict)}, ckpt_path)
+        save_checkpoint(ckpt_path, trainer, train_dict, epoch)
 
-    for epoch in range(start_epoch, cfg.train_iter):                                # reference :120
-        obj_sum = torch.zeros(1, device=device)
-        pending = []
-        for mine, b, gcount in batches:
-            if b is None:      # a rank without instances in this batch still joins the all-reduce
-                trainer.step_empty()
-                continue
-            trainer.global_instances = gcount
-            loss, _ = trainer.step(b)                                               # reference :124-144
-            obj_sum += loss * gcount        # loss is the batch mean over gcount instances (this rank's share)
-            if epoch % log_every == 0:
-                pending.append((mine, trainer._plans[id(b)]["metrics"].clone()))
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(obj_sum)
-        for mine, met in pending:                                                   # reference :146-153
-            met = met.cpu().numpy()
-            for j, gi in enumerate(mine):
-                inst = instances[gi]
-                correct_num, f1 = float(met[j, 0]), float(met[j, 1])
-                out("%8d, %8d, %8d, %5f" % (correct_num, inst.m, inst.n, f1))
-                train_dict[inst.name].append(correct_num)
-        obj = float(obj_sum[0]) / len(instances)
-        train_dict["obj"].append(obj)                  # plain float: the reference's numpy.float32 breaks json.dump
-        if rank == 0:
-            with open("train_log.json", "w") as json_file:                          # reference :155-156
-                json.dump(train_dict, json_file)
-        out(f"epoch {epoch}, obj={obj}")                                            # reference :157
-        if save_every and (epoch + 1) % save_every == 0:
-            save_all(epoch)
+    run_epochs(cfg, instances, train_dict, trainer, batches, rank, world, device, start_epoch, out, save_all)
     save_all(cfg.train_iter - 1)
-    out(f"Model saved to {model_path}.")
+    if rank == 0:
+        out(f"Model saved to {model_path}.")
     return model_path
+
+
+def save_checkpoint(path, trainer, train_dict, epoch):
+    """Everything a restart needs: weights, Adam moments + step counter, the epoch, the log so far."""
+    torch.save({"params": trainer.params, "opt": trainer.opt.state_dict(), "epoch": epoch,
+                "train_dict": json.dumps(train_dict)}, path)
+
+
+def load_checkpoint(path, trainer, train_dict, device):
+    ck = torch.load(path, map_location=device, weights_only=True)
+    trainer.params.copy_(ck["params"])
+    trainer.opt.load_state_dict(ck["opt"])
+    train_dict.update({k: list(v) for k, v in json.loads(ck["train_dict"]).items()})
+    return int(ck["epoch"]) + 1
 
 
 def main(argv=None):

@@ -6,7 +6,7 @@
 CSR(A) + CSR(A^T) behind an opaque `mllp_graph_t*`, and every model call takes it by handle.
 """
 import ctypes
-import os
+import itertools
 from ctypes import c_int32, c_int64, c_double, c_void_p
 from typing import List, Optional, Sequence
 
@@ -17,11 +17,12 @@ from . import _lib
 from .data import LPInstance
 
 
-def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0):
+def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="joint"):
     """Re-block one CSR orientation into the tiled layout of include/mllp_hip.h (mllp_graph_attach_tiled): row tiles
     of R rows x column blocks of CB columns, rows of a (tile, block) ordered by their entry count, entries of the
     four rows of a ds_read_b128 lane group ordered jointly over (column mod 4).  Pure torch, any device (the CPU
-    tests check it against the CSR it came from).  Returns (arrays, info) or None when the matrix does not qualify."""
+    tests check it against the CSR it came from).  `entry_order="perrow"` keeps the simpler per-row round-robin (used
+    by the CPU test that compares the two orders).  Returns (arrays, info) or None when the matrix does not qualify."""
     dev, nnz = idx.device, int(idx.numel())
     if nnz == 0:
         return None
@@ -64,7 +65,7 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0):
     # 64-byte H row covers a quarter of the 256-byte bank row, so four quads reading H rows with equal
     # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).
     cls = ((idx - blk * CB) & 3).long()
-    joint = int(variant) in (0, 1) and R % 16 == 0 and os.environ.get("MLLP_TILED_ORDER", "joint") != "perrow"
+    joint = int(variant) in (0, 1) and R % 16 == 0 and entry_order != "perrow"
     if joint:
         # JOINT ordering of the four rows whose quads share a lane group ({0,3,5,6}, {1,2,4,7}, {8,11,13,14},
         # {9,10,12,15} of the 16 quads that walk positions 16 b .. 16 b + 15): at step p the four rows should
@@ -143,8 +144,11 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0):
 
 
 class LPBatch:
+    _tokens = itertools.count(1)
+
     def __init__(self, handle, M, N, nnz, n_inst, inst_m, inst_n, x1, x2, labels, names=None):
         self._h = handle
+        self.token = next(LPBatch._tokens)     # never reused, unlike id(): keys per-batch caches (LPTrainer._plans)
         self.M, self.N, self.nnz, self.n_inst = int(M), int(N), int(nnz), int(n_inst)
         self.inst_m = [int(v) for v in inst_m]
         self.inst_n = [int(v) for v in inst_n]

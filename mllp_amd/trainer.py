@@ -122,7 +122,7 @@ class LPTrainer:
         self._plans = {}
 
     def _plan(self, batch: LPBatch):
-        key = id(batch)
+        key = batch.token          # unique per LPBatch for the life of the process (id() can be reused after a free)
         p = self._plans.get(key)
         if p is None:
             dev = self.params.device
@@ -135,6 +135,20 @@ class LPTrainer:
                      g_fwd=None, g_opt=None, warm=0, graph=graph)
             self._plans[key] = p
         return p
+
+    def metrics_of(self, batch: LPBatch) -> torch.Tensor:
+        """[n_inst, 2] (correct_num, f1) of the last step on `batch` (with_metrics=True); device tensor."""
+        return self._plans[batch.token]["metrics"]
+
+    def last_loss(self, batch: LPBatch) -> torch.Tensor:
+        return self._plans[batch.token]["loss"]
+
+    def uses_graph(self, batch: LPBatch) -> bool:
+        return bool(self._plans[batch.token]["graph"])
+
+    def release(self, batch: LPBatch):
+        """Drop the buffers (and the reference to the batch) kept for `batch`."""
+        self._plans.pop(batch.token, None)
 
     def _fwd_bwd(self, p):
         b = p["batch"]

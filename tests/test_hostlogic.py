@@ -191,6 +191,96 @@ def test_data_parallel_world2_equals_single_process(tmp_path, subset5):
     np.testing.assert_allclose(got["params"][keep], params[keep], rtol=1e-5, atol=1e-7)
 
 
+_LOOP_WORKER = textwrap.dedent("""
+    import json, os, sys, numpy as np, torch
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    from mllp_amd.config import AttrDict
+    from mllp_amd.data import load_packed, SUBSET5
+    from mllp_amd.experiment import plan_batches, run_epochs, save_checkpoint, load_checkpoint
+    from oracle import pyg_restatement as o1
+    from oracle_trainer import CpuBatch, OracleTrainer
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        rank = dist.get_rank()
+    os.chdir({cwd!r})
+    mode, epochs = sys.argv[1], int(sys.argv[2])
+    inst = load_packed(SUBSET5)
+    cfg = AttrDict(train_iter=epochs, batch_size=2, log_every=1, save_every=0)
+    train_dict = dict(obj=[], **{{i.name: [] for i in inst}})
+    tr = OracleTrainer(o1.flatten_state(o1.init_state(42, torch.float64)))
+    batches = [(mine, CpuBatch([inst[i] for i in mine]) if mine else None, g)
+               for mine, g in plan_batches(inst, 2, rank, world)]
+    start = 0
+    if mode == "resume":
+        start = load_checkpoint("t.ckpt", tr, train_dict, torch.device("cpu"))
+    lines = []
+    run_epochs(cfg, inst, train_dict, tr, batches, rank, world, torch.device("cpu"), start, lines.append)
+    if rank == 0:
+        if mode == "first":
+            save_checkpoint("t.ckpt", tr, train_dict, epochs - 1)
+        np.savez(sys.argv[3], params=tr.params.numpy(), m=tr.opt.m.numpy(), v=tr.opt.v.numpy(),
+                 log=json.dumps(train_dict), lines=json.dumps(lines), file_log=open("train_log.json").read())
+    else:
+        assert lines == [] and not os.path.exists("rank1_wrote_nothing") , lines
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def _run_loop(tmp_path, cwd, mode, epochs, out, nproc=1, port=29641):
+    script = tmp_path / "loop.py"
+    script.write_text(_LOOP_WORKER.format(root=ROOT, cwd=str(cwd)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    if nproc == 1:
+        env.pop("WORLD_SIZE", None)
+        cmd = [sys.executable, str(script), mode, str(epochs), str(out)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), mode, str(epochs), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+def test_driver_loop_world2_log_equals_single_rank(tmp_path):
+    """The experiment driver's epoch loop (shard, step / step_empty, metric gather, log) on 2 gloo ranks writes the
+    SAME train_log.json, prints the same lines (rank 0 only) and ends with the same weights as on 1 rank.
+    batch_size 2 over 5 instances: the last group has one instance, so one rank takes step_empty()."""
+    import json
+    d1, d2 = tmp_path / "w1", tmp_path / "w2"
+    d1.mkdir(); d2.mkdir()
+    one = _run_loop(tmp_path, d1, "straight", 2, tmp_path / "one.npz")
+    two = _run_loop(tmp_path, d2, "straight", 2, tmp_path / "two.npz", nproc=2)
+    log1, log2 = json.loads(str(one["log"])), json.loads(str(two["log"]))
+    assert set(log1) == set(log2) and all(len(v) == 2 for v in log2.values()), log2
+    for k in log1:
+        if k == "obj":
+            np.testing.assert_allclose(log2[k], log1[k], rtol=1e-6)
+        else:
+            assert log2[k] == log1[k], k          # correct counts of EVERY instance, whichever rank owned it
+    assert json.loads(str(two["file_log"])) == log2
+    l1, l2 = json.loads(str(one["lines"])), json.loads(str(two["lines"]))
+    assert len(l1) == len(l2) == 2 * (5 + 1)
+    assert [x for x in l1 if not x.startswith("epoch")] == [x for x in l2 if not x.startswith("epoch")]
+    np.testing.assert_allclose(two["params"], one["params"], rtol=1e-9, atol=1e-12)
+
+
+def test_driver_resume_equals_uninterrupted_run(tmp_path):
+    """2 epochs straight == 1 epoch + checkpoint + resume for 1 more: same log, same weights and Adam moments."""
+    import json
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    d1.mkdir(); d2.mkdir()
+    straight = _run_loop(tmp_path, d1, "straight", 2, tmp_path / "s.npz")
+    _run_loop(tmp_path, d2, "first", 1, tmp_path / "f.npz")
+    resumed = _run_loop(tmp_path, d2, "resume", 2, tmp_path / "r.npz")
+    assert json.loads(str(resumed["log"])) == json.loads(str(straight["log"]))
+    for k in ("params", "m", "v"):
+        np.testing.assert_array_equal(resumed[k], straight[k])
+
+
 def test_root_shims_and_driver_argument_errors(tmp_path, monkeypatch):
     import config as root_config
     import linear_program_data as root_data
@@ -279,9 +369,5 @@ def test_tiled_joint_entry_order_spreads_bank_quarters():
         return tot / steps
     args = (torch.tensor(ptr), torch.tensor(idx), torch.tensor(val), m, 512, 1024, 0)
     joint = cycles(build_tiled_arrays(*args)[0], 512)
-    os.environ["MLLP_TILED_ORDER"] = "perrow"
-    try:
-        perrow = cycles(build_tiled_arrays(*args)[0], 512)
-    finally:
-        del os.environ["MLLP_TILED_ORDER"]
+    perrow = cycles(build_tiled_arrays(*args, entry_order="perrow")[0], 512)
     assert joint < perrow - 0.1 and joint < 1.6, (joint, perrow)

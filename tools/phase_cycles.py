@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of the tiled SpMM kernels (timing build, MLLP_TILED_ABLATION=16).
-usage: python3 tools/phase_cycles.py [instances]     (MLLP_TILED_SPMM=v1 for the previous kernel)"""
+"""Per-phase cycle breakdown of the tiled SpMM kernel.  Needs the TIMING library (`make -C mllp_amd/csrc timing`,
+libmllp_hip_timing.so: cycle counters instead of results under MLLP_TILED_ABLATION=16); the product library has no
+such switch.
+usage: python3 tools/phase_cycles.py [instances]"""
 import os, sys
 os.environ["MLLP_TILED_ABLATION"] = "16"
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+from mllp_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", "libmllp_hip_timing.so")
 from mllp_amd.graph import synthetic_batch
 
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-v1 = os.environ.get("MLLP_TILED_SPMM", "") == "v1"
+v1 = False
 b = synthetic_batch(n_inst)
 for tr in (False, True):
     n_in, n_out = (b.M, b.N) if tr else (b.N, b.M)

@@ -89,6 +89,13 @@ int mllp_graph_dims(const mllp_graph_t* g, int64_t dims[12]);
  *        3 csc_ptr(int32,N+1) 4 csc_idx(int32,nnz) 5 csc_val(f32,nnz) 6 inv_n(f32,N)            */
 int mllp_graph_export(const mllp_graph_t* g, int which, void* host_dst, int64_t capacity_bytes);
 
+/* Which kernels the whole-model entry points (mllp_gnn_forward / _backward / _loss_step) use:
+ *   0  by size (default): the fused latency-regime kernels below 32 M nonzeros (real Netlib: one sweep launch
+ *      per conv forward, two backward, 16 rows per wavefront), the generic / LDS-tiled sweeps above;
+ *   1  always the generic / LDS-tiled sweeps;   2  always the fused kernels.
+ * Both paths compute the same quantities (tests compare them with each other and with the oracle).        */
+int mllp_graph_set_path(mllp_graph_t* g, int path);
+
 /* ------------------------------------------------------------------------------------------------
  * Plain CSR SpMM (the roofline kernel named in BASELINE.json's metric):
  *   transpose == 0:  Y[M,16] = A   * H[N,16]       transpose == 1:  Y[N,16] = A^T * H[M,16]

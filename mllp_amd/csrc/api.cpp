@@ -11,7 +11,7 @@ static inline int64_t up16(int64_t x) { return (x + 15) & ~int64_t(15); }
 int64_t conv_ws_floats(int64_t n, int cin) {
     const int64_t recw = cin == 16 ? REC_W : 8;
     return up16(DERIVED_W) + up16(n * cin) + up16(n) + up16(n * cin) + up16(n * 4) + up16(n * recw) + up16(n * cin) +
-           up16(n * 2) + up16((int64_t)STAT_BLOCKS_MAX * STAT_FLOATS);
+           up16(n * 2) + up16((int64_t)STAT_BLOCKS_MAX * STAT_FLOATS) + up16(STAT_FLOATS);
 }
 
 ConvWs conv_ws_carve(float* base, int64_t n, int cin) {
@@ -26,7 +26,8 @@ ConvWs conv_ws_carve(float* base, int64_t n, int cin) {
     w.rec = p; p += up16(n * recw);
     w.dqp = p; p += up16(n * cin);
     w.dsdt = p; p += up16(n * 2);
-    w.stats = p;
+    w.stats = p; p += up16((int64_t)STAT_BLOCKS_MAX * STAT_FLOATS);
+    w.red = p;
     return w;
 }
 
@@ -71,6 +72,7 @@ struct ModelWs {
     ConvWs c1v, c1c, c2v, c2c, c3v;
     float *h1v, *h1c, *h2v, *h2c, *h3v;
     float *d3v, *d2v, *d2c, *d1v, *d1c;
+    float *d1v_b, *d1c_b;       // second contributions to dL/dh1 (fused path: separate buffers instead of +=)
     float* head_partials;
     int64_t total;
 };
@@ -100,6 +102,7 @@ static ModelWs model_ws(const mllp_graph* g, float* base) {
     w.h3v = buf(N * 16);
     w.d3v = buf(N * 16); w.d2v = buf(N * 16); w.d2c = buf(M * 16);
     w.d1v = buf(N * 16); w.d1c = buf(M * 16);
+    w.d1v_b = buf(N * 16); w.d1c_b = buf(M * 16);
     w.head_partials = buf(HEAD_PART_FLOATS);
     w.total = p - base;
     return w;
@@ -231,6 +234,26 @@ static int model_backward_body(const mllp_graph* g, const float* P, const float*
     return launch_finalize_batch(MODEL_CONVS, cps, cins, sts, nbs, grs, grads + OFF_C3C, OFF_FC - OFF_C3C, s);
 }
 
+// ---- fused latency-regime path ------------------------------------------------------------------------
+static bool use_fused(const mllp_graph* g) {
+    if (g->path == 1) return false;
+    if (g->path == 2) return true;
+    return g->nnz < ((int64_t)32 << 20);     // the throughput regime keeps the generic / LDS-tiled sweeps
+}
+
+static FusedModel fused_model(const mllp_graph* g, const float* P, const float* x1, const float* x2, const ModelWs& w,
+                              const float* labels, float inv_batch, float* logits) {
+    (void)g;
+    FusedModel m = {};
+    m.cp[0] = P + OFF_C1V; m.cp[1] = P + OFF_C1C; m.cp[2] = P + OFF_C2V; m.cp[3] = P + OFF_C2C; m.cp[4] = P + OFF_C3V;
+    m.c[0] = w.c1v; m.c[1] = w.c1c; m.c[2] = w.c2v; m.c[3] = w.c2c; m.c[4] = w.c3v;
+    m.x1 = x1; m.x2 = x2; m.fcw = P + OFF_FC; m.fcb = P + OFF_FC + 16; m.labels = labels; m.inv_batch = inv_batch;
+    m.h1v = w.h1v; m.h1c = w.h1c; m.h2v = w.h2v; m.h2c = w.h2c; m.h3v = w.h3v;
+    m.d3v = w.d3v; m.d2v = w.d2v; m.d2c = w.d2c; m.d1v = w.d1v; m.d1c = w.d1c; m.d1v_b = w.d1v_b; m.d1c_b = w.d1c_b;
+    m.logits = logits; m.head_part = w.head_partials;
+    return m;
+}
+
 }  // namespace mllp
 
 using namespace mllp;
@@ -242,6 +265,13 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
     REQUIRE(g && d_H && d_Y, "null argument");
     const Orient& o = transpose ? g->At : g->A;
     return launch_spmm(o, d_H, d_Y, o.scratch, (hipStream_t)stream);
+}
+
+extern "C" int mllp_graph_set_path(mllp_graph_t* g, int path) {
+    REQUIRE(g, "null graph");
+    REQUIRE(path >= 0 && path <= 2, "path must be 0 (by size), 1 (generic / LDS-tiled sweeps) or 2 (fused latency-regime kernels)");
+    g->path = path;
+    return MLLP_OK;
 }
 
 extern "C" int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block,
@@ -318,6 +348,8 @@ extern "C" int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, co
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    if (use_fused(g))
+        return fused_forward(g, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
     return launch_head(0, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f, nullptr,
                        d_logits, nullptr, w.head_partials, s);
@@ -331,6 +363,11 @@ extern "C" int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, c
     int rc;
     if ((rc = launch_head(1, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f,
                           d_dlogits, nullptr, w.d3v, w.head_partials, s))) return rc;
+    if (use_fused(g)) {
+        if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, s))) return rc;
+        return fused_backward(g, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, nullptr), false, d_grads,
+                              nullptr, s);
+    }
     if ((rc = fork_to(s, g->aux, g->ev[1]))) return rc;
     if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, g->aux))) return rc;
     return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
@@ -343,6 +380,11 @@ extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, 
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    if (use_fused(g)) {
+        const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, d_labels, inv_batch, d_logits);
+        if ((rc = fused_forward(g, m, 2, s))) return rc;
+        return fused_backward(g, m, true, d_grads, d_loss, s);
+    }
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
     if ((rc = launch_head(2, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, d_labels, inv_batch,
                           nullptr, d_logits, w.d3v, w.head_partials, s))) return rc;

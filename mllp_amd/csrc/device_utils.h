@@ -114,4 +114,58 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
     return base + (b >> 3);
 }
 
+// all-reduce over the quads of a G-lane group, for values that are replicated or owned per `part`
+// (lanes 4 apart hold the same channel): G = 16 -> rotate by 8 and 4 inside the DPP row
+template <int G>
+__device__ __forceinline__ float quads_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    if (G == 64) {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float quads_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    if (G == 64) {
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+    }
+    return v;
+}
+// sum over the 4 lanes of a quad (every lane gets the total)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+// value held by lane J of the own quad
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return dpp_mov<J * 0x55>(v);   // quad_perm [J,J,J,J]
+}
+// all 16 channels from the 4 per-part float4 of a quad
+__device__ __forceinline__ void quad_allgather(const float4& v, float (&r)[16]) {
+    r[0] = quad_bcast<0>(v.x);  r[1] = quad_bcast<0>(v.y);  r[2] = quad_bcast<0>(v.z);  r[3] = quad_bcast<0>(v.w);
+    r[4] = quad_bcast<1>(v.x);  r[5] = quad_bcast<1>(v.y);  r[6] = quad_bcast<1>(v.z);  r[7] = quad_bcast<1>(v.w);
+    r[8] = quad_bcast<2>(v.x);  r[9] = quad_bcast<2>(v.y);  r[10] = quad_bcast<2>(v.z); r[11] = quad_bcast<2>(v.w);
+    r[12] = quad_bcast<3>(v.x); r[13] = quad_bcast<3>(v.y); r[14] = quad_bcast<3>(v.z); r[15] = quad_bcast<3>(v.w);
+}
+
+// exp(x) for x <= ~0 with ~1-2 ulp: hardware 2^t (v_exp_f32) on t = x*log2(e), with the rounding error
+// of that product (and of the constant) fed back as a first-order correction.  The plain
+// v_exp_f32(x * log2e) loses |x| * 6e-8 relative accuracy, too much against the 1e-5 parity budget.
+__device__ __forceinline__ float exp_acc(float x) {
+    const float L2E_HI = 1.44269502163e+00f, L2E_LO = 1.92596299112e-08f, LN2 = 0.693147180560f;
+    x = fmaxf(x, -150.0f);   // exp(-150) is exactly 0 in fp32; keeps NEG_BIG sentinels away from inf - inf
+    const float t = x * L2E_HI;
+    float r = fmaf(x, L2E_HI, -t);
+    r = fmaf(x, L2E_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * LN2, e);
+}
+
 }  // namespace mllp

@@ -58,6 +58,10 @@ static int build_tiers(mllp_graph* g, Orient& o, const int* h_ptr) {
     if ((rc = upload(g, t.rows_wave.data(), t.rows_wave.size(), &o.rows_wave))) return rc;
     if ((rc = upload(g, t.chunks.data(), t.chunks.size(), &o.chunks))) return rc;
     if ((rc = upload(g, t.split.data(), t.split.size(), &o.split))) return rc;
+    HostItems it;
+    host_build_items(h_ptr, o.n_dst, ITEM_QUAD_MAX_DEG, ITEM_WAVE_MAX_DEG, &it);
+    o.n_iblock = it.n_block; o.n_iwave = it.n_wave; o.n_iquad = it.n_quad;
+    if ((rc = upload(g, it.rows.data(), it.rows.size(), &o.item_rows))) return rc;
     return MLLP_OK;
 }
 
@@ -81,6 +85,12 @@ static int finish_common(mllp_graph* g) {
         MLLP_HIP_TRY(hipMalloc(&p, (size_t)std::max(o->n_slots, 1) * SCRATCH_NS * sizeof(float)));
         g->allocs.push_back(p);
         o->scratch = static_cast<float*>(p);
+    }
+    {
+        int dev = 0, cus = 0;
+        MLLP_HIP_TRY(hipGetDevice(&dev));
+        MLLP_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g->n_cu = cus > 0 ? cus : 256;
     }
     MLLP_HIP_TRY(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
     for (auto& e : g->ev) MLLP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

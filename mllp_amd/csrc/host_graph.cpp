@@ -134,4 +134,26 @@ void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTier
     t.short_rows = n_dst > 0 && (double)ptr[n_dst] / n_dst <= 16.0;
 }
 
+void host_build_items(const int* ptr, int n_dst, int quad_max_deg, int wave_max_deg, HostItems* out) {
+    HostItems& t = *out;
+    t = HostItems();
+    t.rows.resize((size_t)std::max(n_dst, 0));
+    if (n_dst <= 0) return;
+    // counting sort by degree, descending, stable in the row index.  Degrees above the wave tier's limit only
+    // need their relative order among few rows: sorted separately.
+    const int cap = wave_max_deg + 1;                       // bucket `cap` holds every longer row
+    std::vector<int> cnt((size_t)cap + 2, 0);
+    for (int r = 0; r < n_dst; ++r) cnt[std::min(ptr[r + 1] - ptr[r], cap)]++;
+    std::vector<int> start((size_t)cap + 2, 0);             // first position of each bucket, longest first
+    int pos = 0;
+    for (int d = cap; d >= 0; --d) { start[d] = pos; pos += cnt[d]; }
+    t.n_block = cnt[cap];
+    for (int d = cap - 1; d > quad_max_deg; --d) t.n_wave += cnt[d];
+    t.n_quad = n_dst - t.n_block - t.n_wave;
+    std::vector<int> fill(start);
+    for (int r = 0; r < n_dst; ++r) t.rows[fill[std::min(ptr[r + 1] - ptr[r], cap)]++] = r;
+    std::stable_sort(t.rows.begin(), t.rows.begin() + t.n_block,
+                     [&](int a, int b) { return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b]; });
+}
+
 }  // namespace mllp

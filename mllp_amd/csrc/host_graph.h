@@ -40,4 +40,18 @@ struct HostTiers {
 };
 void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTiers* out);
 
+// Work list of the fused latency-regime kernels (fused_kernels.hip): the rows of one orientation ordered by their
+// number of nonzeros, descending (ties in row order), cut in three tiers:
+//   block tier  deg > wave_max_deg    one whole workgroup walks the row
+//   wave tier   deg > quad_max_deg    one wavefront walks the row
+//   quad tier   the rest (incl. empty rows): 16 rows per wavefront (16-channel sweeps: a quad of lanes per row) or
+//               64 rows per wavefront (1-channel sweeps: a lane per row); neighbours in the order have equal or
+//               nearly equal length, so the lanes of a wavefront finish together
+struct HostItems {
+    std::vector<int> rows;    // [n_dst]
+    int n_block = 0, n_wave = 0, n_quad = 0;
+};
+constexpr int ITEM_QUAD_MAX_DEG = 32, ITEM_WAVE_MAX_DEG = 512;
+void host_build_items(const int* ptr, int n_dst, int quad_max_deg, int wave_max_deg, HostItems* out);
+
 }  // namespace mllp

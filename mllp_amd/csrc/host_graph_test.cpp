@@ -124,6 +124,26 @@ static void check_tiers(const int* ptr, int n_dst, const TierConfig& c) {
     CHECK(n_group == t.n_group);
 }
 
+static void check_items(const int* ptr, int n_dst, int qmax, int wmax) {
+    HostItems t;
+    host_build_items(ptr, n_dst, qmax, wmax, &t);
+    CHECK((int)t.rows.size() == n_dst && t.n_block + t.n_wave + t.n_quad == n_dst);
+    std::vector<int> seen(n_dst, 0);
+    int prev = 1 << 30, prev_row = -1;
+    for (int k = 0; k < n_dst; ++k) {
+        const int r = t.rows[k];
+        CHECK(r >= 0 && r < n_dst && !seen[r]);
+        seen[r] = 1;
+        const int deg = ptr[r + 1] - ptr[r];
+        CHECK(deg <= prev);                                   // descending
+        if (deg == prev) CHECK(r > prev_row);                 // ties in row order
+        if (k < t.n_block) CHECK(deg > wmax);
+        else if (k < t.n_block + t.n_wave) CHECK(deg > qmax && deg <= wmax);
+        else CHECK(deg <= qmax);
+        prev = deg; prev_row = r;
+    }
+}
+
 int main() {
     std::mt19937 rng(12345);
     for (int round = 0; round < 6; ++round) {
@@ -141,6 +161,12 @@ int main() {
                 CHECK(c.tier_block >= c.tier_wave && c.chunk_nnz == 4 * c.tier_block);
                 check_tiers(b.csr_ptr.data(), (int)b.M, c);
                 check_tiers(b.csc_ptr.data(), (int)b.N, c);
+            }
+        for (int qm : {0, 2, 32})
+            for (int wm : {2, 40, 512}) {
+                if (wm < qm) continue;
+                check_items(b.csr_ptr.data(), (int)b.M, qm, wm);
+                check_items(b.csc_ptr.data(), (int)b.N, qm, wm);
             }
     }
     {   // empty batch and argument errors

@@ -59,6 +59,9 @@ struct Orient {
     float* scratch = nullptr;   // [n_slots x SCRATCH_NS] partial states of this orientation's split rows
     int tier_wave = 0;          // rows with more nonzeros than this are skipped by the group tier
     bool short_rows = false;    // mean row length <= 16: group tier runs one nonzero slot per pass
+    // work list of the fused latency-regime kernels (host_graph.h::HostItems): rows by length, three tiers
+    int* item_rows = nullptr;   // [n_dst]
+    int n_iblock = 0, n_iwave = 0, n_iquad = 0;
 };
 constexpr int SCRATCH_NS = 20;  // floats per partial-state slot of a split row
 
@@ -74,6 +77,8 @@ struct mllp_graph {
     std::vector<int64_t> h_inst_ptr_n, h_inst_ptr_m;
     int tier_wave = 0, tier_block = 0, chunk_nnz = 0;
     int max_inst_n = 0;
+    int n_cu = 256;              // compute units of the device: grid size of the persistent fused kernels
+    int path = 0;                // whole-model path: 0 = by size (fused below 32 M nonzeros), 1 = generic / tiled, 2 = fused
     // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
     // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
     hipStream_t aux = nullptr;
@@ -125,6 +130,7 @@ struct ConvWs {
     float* dqp;      // [n_dst, cin]
     float* dsdt;     // [n_dst, 2]
     float* stats;    // [STAT_BLOCKS_MAX, STAT_FLOATS] per-workgroup partial statistics
+    float* red;      // [STAT_FLOATS] the summed statistics (fused path)
 };
 int64_t conv_ws_floats(int64_t n_dst, int cin);
 ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
@@ -175,5 +181,22 @@ int launch_adam(float* p, const float* g, float* m, float* v, float* state, floa
 int launch_fill_zero(float* p, int64_t n, hipStream_t s);
 int launch_topm_metrics(const mllp_graph* g, const float* logits, const float* labels, void* scratch, float* out,
                         hipStream_t s);
+
+// ---- fused latency-regime path of the whole model (fused_kernels.hip) ---------------------------------
+struct FusedModel {
+    const float* cp[MODEL_CONVS];   // parameters of gconv1_w2s, gconv1_s2w, gconv2_w2s, gconv2_s2w, gconv3_w2s
+    ConvWs c[MODEL_CONVS];
+    const float *x1, *x2, *fcw, *fcb, *labels;
+    float inv_batch;
+    float *h1v, *h1c, *h2v, *h2c, *h3v;
+    float *d3v, *d2v, *d2c, *d1v, *d1c, *d1v_b, *d1c_b;
+    float *logits, *head_part;
+};
+int fused_grid(const mllp_graph* g);
+// head_mode 1: logits (h3v kept), 2: logits + BCE + masked dL/dh3v in d3v + fc partials
+int fused_forward(const mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s);
+// premasked: d3v and the fc partials come from fused_forward(head_mode 2); else d3v = dL/dh3v (unmasked) and the
+// caller has produced the fc gradient itself
+int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s);
 
 }  // namespace mllp

@@ -145,6 +145,9 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
 
 class LPBatch:
     _tokens = itertools.count(1)
+    # whole-model kernels: 0 = by size (fused latency-regime kernels below 32 M nonzeros, generic / LDS-tiled sweeps
+    # above), 1 = always generic / tiled, 2 = always fused (mllp_graph_set_path).  Tests set the class default.
+    default_path = 0
 
     def __init__(self, handle, M, N, nnz, n_inst, inst_m, inst_n, x1, x2, labels, names=None):
         self._h = handle
@@ -156,6 +159,13 @@ class LPBatch:
         self.names = list(names) if names is not None else [f"inst{i}" for i in range(n_inst)]
         self._ws = None
         self._n_off = np.concatenate([[0], np.cumsum(self.inst_n)]).astype(np.int64)
+        if LPBatch.default_path:
+            self.set_path(LPBatch.default_path)
+
+    def set_path(self, path):
+        """0 = by size, 1 = generic / LDS-tiled sweeps, 2 = fused latency-regime kernels (whole-model calls only)."""
+        _lib.check(_lib.lib().mllp_graph_set_path(self._h, int(path)))
+        return self
 
     # ---- construction ------------------------------------------------------------------------
     @staticmethod

@@ -49,13 +49,17 @@ def grad_mask():
     return keep
 
 
-@pytest.fixture(scope="module")
-def LPBatch():
+@pytest.fixture(scope="module", params=["auto", "generic"])
+def LPBatch(request):
+    """Every test that builds batches runs twice: with the library's own choice of whole-model kernels (the fused
+    latency-regime path for everything below 32 M nonzeros) and with the generic / LDS-tiled sweeps forced."""
     from mllp_amd import _lib
     _lib.lib()                      # fail loudly: no fallback
     assert torch.cuda.is_available()
     from mllp_amd.graph import LPBatch as cls
-    return cls
+    cls.default_path = 1 if request.param == "generic" else 0
+    yield cls
+    cls.default_path = 0
 
 
 @pytest.fixture(scope="module")
@@ -724,3 +728,29 @@ def test_experiment_driver_resume(tmp_path, monkeypatch):
     for k in ("m", "v", "state"):
         assert torch.equal(ck_r["opt"][k], ck_s["opt"][k]), k
     assert list(sd_r) == list(sd_s) and all(torch.equal(sd_r[k], sd_s[k]) for k in sd_s)
+
+
+def test_fused_path_equals_generic_path(LPBatch, weights):
+    """The two whole-model paths on the same batches: all 97 Netlib instances (every tier of both: rows of 0 .. 6184
+    nonzeros) and a ragged synthetic batch; forward-only logits, loss-step logits / loss / gradients, and the
+    backward-from-dlogits entry point that GNNModel's autograd function uses."""
+    flat, sd, flat_gpu = weights
+    from mllp_amd.graph import synthetic_batch
+    inst = load_packed()
+    for make in (lambda: LPBatch.from_instances(inst),
+                 lambda: LPBatch.from_instances([_holes_instance(11, 300, 700), _holes_instance(12, 1, 40),
+                                                 _holes_instance(13, 900, 30)]),
+                 lambda: synthetic_batch(n_inst=3, m=700, n=1300, mean_row_nnz=40.0, seed=5, chunk=2)):
+        bg, bf = make().set_path(1), make().set_path(2)
+        lg, zg, gg = [t.clone() for t in bg.loss_step(flat_gpu)]
+        lf, zf, gf = [t.clone() for t in bf.loss_step(flat_gpu)]
+        close(zf.cpu().numpy(), zg.cpu().numpy(), RTOL_ACT, "logits fused vs generic")
+        close(lf.cpu().numpy(), lg.cpu().numpy(), RTOL_ACT, "loss fused vs generic")
+        close(gf.cpu().numpy()[grad_mask()], gg.cpu().numpy()[grad_mask()], RTOL_GRAD, "grads fused vs generic")
+        l2, z2, g2 = bf.loss_step(flat_gpu)
+        assert torch.equal(z2, zf) and torch.equal(g2, gf) and torch.equal(l2, lf)       # bitwise run to run
+        close(bf.forward(flat_gpu).cpu().numpy(), zg.cpu().numpy(), RTOL_ACT, "forward-only logits")
+        dz = torch.randn(bf.N, device="cuda") / bf.N
+        bg.forward(flat_gpu)
+        close(bf.backward(flat_gpu, dz).cpu().numpy()[grad_mask()], bg.backward(flat_gpu, dz).cpu().numpy()[grad_mask()],
+              RTOL_GRAD, "backward from dlogits, fused vs generic")

@@ -236,7 +236,7 @@ static int model_backward_body(const mllp_graph* g, const float* P, const float*
 
 // ---- fused latency-regime path ------------------------------------------------------------------------
 static bool use_fused(const mllp_graph* g) {
-    if (g->path == 1) return false;
+    if (g->path == 1 || !g->fused_built) return false;
     if (g->path == 2) return true;
     return g->nnz < ((int64_t)32 << 20);     // the throughput regime keeps the generic / LDS-tiled sweeps
 }
@@ -251,6 +251,7 @@ static FusedModel fused_model(const mllp_graph* g, const float* P, const float* 
     m.h1v = w.h1v; m.h1c = w.h1c; m.h2v = w.h2v; m.h2c = w.h2c; m.h3v = w.h3v;
     m.d3v = w.d3v; m.d2v = w.d2v; m.d2c = w.d2c; m.d1v = w.d1v; m.d1c = w.d1c; m.d1v_b = w.d1v_b; m.d1c_b = w.d1c_b;
     m.logits = logits; m.head_part = w.head_partials;
+    m.have_head_part = true;
     return m;
 }
 
@@ -270,6 +271,10 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
 extern "C" int mllp_graph_set_path(mllp_graph_t* g, int path) {
     REQUIRE(g, "null graph");
     REQUIRE(path >= 0 && path <= 2, "path must be 0 (by size), 1 (generic / LDS-tiled sweeps) or 2 (fused latency-regime kernels)");
+    if (path == 2 && !g->fused_built) {        // (allocates: not a launch function)
+        const int rc = fused_graph_build(g, g->h_csr_ptr.data(), g->h_csc_ptr.data());
+        if (rc) return rc;
+    }
     g->path = path;
     return MLLP_OK;
 }
@@ -349,7 +354,7 @@ extern "C" int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, co
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
     if (use_fused(g))
-        return fused_forward(g, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
+        return fused_forward(const_cast<mllp_graph*>(g), fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
     return launch_head(0, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f, nullptr,
                        d_logits, nullptr, w.head_partials, s);
@@ -361,13 +366,13 @@ extern "C" int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, c
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    if (use_fused(g)) {      // (the node tensors of the fused path are in renumbered order: it has its own head kernel)
+        const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, nullptr);
+        if ((rc = fused_head_backward(g, m, d_dlogits, s))) return rc;
+        return fused_backward(g, m, false, d_grads, nullptr, s);
+    }
     if ((rc = launch_head(1, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f,
                           d_dlogits, nullptr, w.d3v, w.head_partials, s))) return rc;
-    if (use_fused(g)) {
-        if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, s))) return rc;
-        return fused_backward(g, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, nullptr), false, d_grads,
-                              nullptr, s);
-    }
     if ((rc = fork_to(s, g->aux, g->ev[1]))) return rc;
     if ((rc = launch_head_finalize(w.head_partials, head_blocks_for(g->N), d_grads + OFF_FC, nullptr, g->aux))) return rc;
     return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
@@ -382,7 +387,7 @@ extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, 
     int rc;
     if (use_fused(g)) {
         const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, d_labels, inv_batch, d_logits);
-        if ((rc = fused_forward(g, m, 2, s))) return rc;
+        if ((rc = fused_forward(const_cast<mllp_graph*>(g), m, 2, s))) return rc;
         return fused_backward(g, m, true, d_grads, d_loss, s);
     }
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;

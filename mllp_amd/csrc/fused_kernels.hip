@@ -3,26 +3,34 @@
 // Why a second set of kernels: on the Netlib batch (1.07 M nonzeros, 366 k nodes, median row length 2-4) a training
 // step of the generic path is ~45 launches whose sweeps are bound by dependent memory round trips at low occupancy
 // (profiles/r01_netlib_kernel_stats.md: 91 us for a 1 M-nonzero attention sweep, 68 % of wave time in s_waitcnt), and
-// per conv it writes and re-reads q', t, dq', ds/dt and a separate statistics pass.  Here a conv is ONE sweep launch
-// forward (weight folding products, q' = Pq x, the attention sweep, the output GEMMs, ReLU -- and for the last conv
-// fc + BCEWithLogits + dL/dh) and TWO backward (destination-major: ReLU mask, gv = Wv^T g, record, sweep, input
-// gradient, parameter statistics on the MFMA; source-major: the transposed sweep), and the two convs of a layer /
-// the independent sweeps of the backward chain share launches.  reference: linear_program_methods.py:238-251,
-// linear_program_experiment.py:139-141; formulas SURVEY.md appendix A.3 / A.4 (oracle/spmm_form.py).
+// per conv it writes and re-reads q', t, dq', ds/dt and runs a separate statistics pass.  Here a conv is ONE sweep
+// launch forward (q' = Pq x, the attention sweep, the output GEMMs, ReLU -- and for the last conv fc +
+// BCEWithLogits + dL/dh) and TWO backward (destination-major: ReLU mask, gv = Wv^T g, record, sweep, input gradient,
+// parameter statistics on the MFMA; source-major: the transposed sweep); the two convs of a layer share a launch.
+// reference: linear_program_methods.py:238-251, linear_program_experiment.py:139-141; formulas SURVEY.md appendix
+// A.3 / A.4 (oracle/spmm_form.py).
 //
-// Mapping: persistent workgroups of 1024 threads, one per CU.  Rows of an orientation are ordered by length
-// (host_graph.h::HostItems); a WAVEFRONT takes an item = 16 rows of (nearly) equal length, one QUAD of lanes per row
-// (lane `part` owns channels 4 part .. 4 part + 3; a gather of a 64-byte source row is one 16-byte load per lane of
-// the quad), so 16 rows and up to 64 gathers are in flight per wavefront -- four times the rows per wave of the
-// generic 16-lanes-per-row tier.  Rows longer than 32 nonzeros take a whole wavefront (16 quads stride the row,
-// states merged by DPP / shuffles), rows longer than 512 the whole workgroup (merged through LDS).  Scalar (layer-1)
-// convs use one LANE per row.  The 16x16 per-node GEMMs run in the quad layout: the 16 inputs of a row are spread
-// over the quad, fetched with quad_perm DPP, weights come from LDS (rows padded to 80 bytes so that the four parts
-// read four different bank groups).  Nothing here uses atomics: partial sums have a fixed owner and a fixed order, so
-// two runs give identical bits.
+// Data: the path works in RENUMBERED node ids (host_graph.h::HostFusedOrient): constraints ordered by row length,
+// variables by column length, descending.  Row k of a sweep is node k, so every per-node tensor of the model is
+// read and written with unit stride, the rows a wavefront shares have (nearly) equal length, and the row tiers are
+// contiguous id ranges.  Both orientations are stored once in that numbering as {source id, value} pairs; the
+// inputs (coefs, rhs, labels) are copied into it when they are bound, and because layer 1's node features ARE the
+// inputs, its per-nonzero source feature is stored beside the value ({a_ij, x_j}): the layer-1 sweeps gather
+// nothing.  Only the logits leave in the caller's variable order.
+//
+// Mapping: persistent workgroups of 1024 threads, one per CU.  A WAVEFRONT takes an item = 16 rows, one QUAD of
+// lanes per row (lane `part` owns channels 4 part .. 4 part + 3; a gather of a 64-byte source row is one 16-byte
+// load per lane of the quad): 16 rows and 64 gathers in flight per wavefront, and the entries of the next four
+// nonzeros are fetched while the current four are gathered.  Rows longer than 16 nonzeros take 4 quads, longer than
+// 64 a whole wavefront, longer than 1024 the whole workgroup (states merged by DPP / shuffles / LDS).  Scalar
+// (layer-1) sweeps use one LANE per row.  The 16x16 per-node GEMMs and the parameter statistics run on the MFMA
+// (v_mfma_f32_16x16x4_f32, exact fp32) through LDS tiles that convert between the quad layout and the MFMA layouts.
+// Nothing here uses atomics: partial sums have a fixed owner and a fixed order, so two runs give identical bits.
 #include <algorithm>
+#include <vector>
 
 #include "device_utils.h"
+#include "host_graph.h"
 #include "internal.h"
 
 namespace mllp {
@@ -31,26 +39,35 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 constexpr int FT = 1024;            // threads per workgroup
 constexpr int FW = FT / 64;         // wavefronts per workgroup
-constexpr int WSTR = 20;            // floats per padded 16-float weight row in LDS
 constexpr int MAXJOBS = 2;
 
+constexpr int NP = FUSED_NP;        // partitions (one per XCD: workgroup b works on partition b % NP)
+static_assert(NP == FUSED_PARTS, "partition count");
+
+struct PartTiers {
+    int row0, n_block, n_wave, n_group, n_base;
+};
 struct ItemsDev {
-    const int* __restrict__ ptr;
-    const int* __restrict__ idx;
-    const float* __restrict__ val;
-    const int* __restrict__ rows;   // rows by length, descending: [block tier | wave tier | quad tier]
-    int n_dst, n_block, n_wave, n_quad;
+    const int* __restrict__ sptr;    // [n_dst + 1]
+    const int2* __restrict__ sent;   // [nnz] {source id, value bits}
+    const float2* __restrict__ sax;  // [nnz] {a, x_src} (layer 1)
+    int n_dst;
+    PartTiers part[NP];
 };
 
-static ItemsDev items_dev(const Orient& o) {
+static ItemsDev items_dev(const FusedOrient& o, bool scalar) {
     ItemsDev d;
-    d.ptr = o.ptr; d.idx = o.idx; d.val = o.val; d.rows = o.item_rows;
-    d.n_dst = o.n_dst; d.n_block = o.n_iblock; d.n_wave = o.n_iwave; d.n_quad = o.n_iquad;
+    d.sptr = o.sptr;
+    d.sent = reinterpret_cast<const int2*>(o.sent);
+    d.sax = reinterpret_cast<const float2*>(o.sax);
+    d.n_dst = o.n_dst;
+    for (int q = 0; q < NP; ++q) {
+        const FusedTiersDev& t = scalar ? o.t1[q] : o.t16[q];
+        d.part[q].row0 = o.row0[q];
+        d.part[q].n_block = t.n_block; d.part[q].n_wave = t.n_wave; d.part[q].n_group = t.n_group; d.part[q].n_base = t.n_base;
+    }
     return d;
 }
-
-__device__ __forceinline__ int wave_items16(const ItemsDev& s) { return s.n_wave + ((s.n_quad + 15) >> 4); }
-__device__ __forceinline__ int wave_items64(const ItemsDev& s) { return s.n_wave + ((s.n_quad + 63) >> 6); }
 
 // ---- 16x16 per-node GEMMs on the MFMA, rows of a wavefront through an LDS tile ---------------------------
 // A wavefront's item is 16 rows x 16 channels, held in the QUAD layout (lane 4 q + p: row q, channels 4 p .. 4 p + 3).
@@ -131,50 +148,77 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+
 // which rows a wavefront works on: an item of the wave loop, or a block-tier row shared by the workgroup
 struct RowSlot {
     int row;      // -1: no row for this quad / lane
-    int first;    // index of this quad's (lane's) first nonzero
+    int first;    // index of this unit's first nonzero
     int stride;   // distance between its nonzeros
     int end;      // end of the row
-    int mode;     // 0 = row per quad (lane), 1 = row per wavefront, 2 = row per workgroup
+    int mode;     // 0 = row per unit (quad / lane), 1 = row per group of units, 2 = row per wavefront, 3 = per workgroup
+    bool writer;  // this unit stores the row's results (and counts it in the statistics)
 };
-// G lanes per row in the quad tier: 4 (16-channel sweeps) or 1 (scalar sweeps)
+// G lanes per unit: 4 (16-channel sweeps: a quad) or 1 (scalar sweeps: a lane)
 template <int G>
-__device__ __forceinline__ RowSlot item_slot(const ItemsDev& s, int item, int lane) {
-    constexpr int RPW = 64 / G;                    // rows per wavefront in the quad tier
-    const int unit = lane / G;                     // quad (or lane) inside the wavefront
+struct Geo {
+    static constexpr int U = 64 / G;              // units per wavefront
+    static constexpr int QG = G == 4 ? 4 : 16;    // units per row in the group tier (always 16 lanes = one DPP row)
+    static constexpr int RG = U / QG;             // rows per wavefront in the group tier
+};
+template <int G>
+__device__ __forceinline__ int wave_items(const PartTiers& s) {
+    return s.n_wave + (s.n_group + Geo<G>::RG - 1) / Geo<G>::RG + (s.n_base + Geo<G>::U - 1) / Geo<G>::U;
+}
+template <int G>
+__device__ __forceinline__ RowSlot item_slot(const ItemsDev& S, const PartTiers& s, int item, int lane) {
+    constexpr int U = Geo<G>::U, QG = Geo<G>::QG, RG = Geo<G>::RG;
+    const int unit = lane / G;
+    const int n_gitems = (s.n_group + RG - 1) / RG;
     RowSlot r;
+    int q;
+    bool valid;
     if (item < s.n_wave) {
-        r.row = s.rows[s.n_block + item];
-        r.mode = 1;
-        r.first = s.ptr[r.row] + unit;
-        r.stride = RPW;
-        r.end = s.ptr[r.row + 1];
+        r.row = s.row0 + s.n_block + item; q = unit; r.stride = U; r.mode = 2; valid = true; r.writer = unit == 0;
+    } else if (item < s.n_wave + n_gitems) {
+        const int rl = (item - s.n_wave) * RG + unit / QG;
+        valid = rl < s.n_group;
+        r.row = s.row0 + s.n_block + s.n_wave + rl; q = unit % QG; r.stride = QG; r.mode = 1; r.writer = valid && q == 0;
     } else {
-        const int k = s.n_block + s.n_wave + (item - s.n_wave) * RPW + unit;
-        r.mode = 0;
-        r.stride = 1;
-        if (k < s.n_dst) {
-            r.row = s.rows[k];
-            r.first = s.ptr[r.row];
-            r.end = s.ptr[r.row + 1];
-        } else {
-            r.row = -1; r.first = 0; r.end = 0;
-        }
+        const int rl = (item - s.n_wave - n_gitems) * U + unit;
+        valid = rl < s.n_base;
+        r.row = s.row0 + s.n_block + s.n_wave + s.n_group + rl; q = 0; r.stride = 1; r.mode = 0; r.writer = valid;
+    }
+    if (valid) {
+        r.first = S.sptr[r.row] + q;
+        r.end = S.sptr[r.row + 1];
+    } else {
+        r.row = -1; r.first = 0; r.end = 0;
     }
     return r;
 }
 template <int G>
-__device__ __forceinline__ RowSlot block_slot(const ItemsDev& s, int k, int tid) {
+__device__ __forceinline__ RowSlot block_slot(const ItemsDev& s, int k, int tid) {     // k: renumbered row id
     RowSlot r;
-    r.row = s.rows[k];
-    r.mode = 2;
-    r.first = s.ptr[r.row] + tid / G;
+    r.row = k;
+    r.mode = 3;
+    r.first = s.sptr[k] + tid / G;
     r.stride = FT / G;
-    r.end = s.ptr[r.row + 1];
+    r.end = s.sptr[k + 1];
+    r.writer = tid < G;
     return r;
 }
+__device__ __forceinline__ int slot_count(const RowSlot& r) {
+    return r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
+}
+// sums / maxima over the units that share a row (quad layout: values replicated inside a quad or owned per part)
+__device__ __forceinline__ float shared_sum4(float v, int mode) {
+    return mode == 1 ? quads_sum<16>(v) : quads_sum<64>(v);
+}
+__device__ __forceinline__ float shared_max4(float v, int mode) {
+    return mode == 1 ? quads_max<16>(v) : quads_max<64>(v);
+}
+__device__ __forceinline__ float shared_sum1(float v, int mode) { return mode == 1 ? row16_sum(v) : wave_sum(v); }
+__device__ __forceinline__ float shared_max1(float v, int mode) { return mode == 1 ? row16_max(v) : group_max<64>(v); }
 
 // ====================================================================================================
 // forward, 16 source channels
@@ -191,10 +235,11 @@ struct FwdJob16 {
     int head;                          // 0: plain conv, 1: + logits, 2: + BCEWithLogits, dL/dh (masked) and fc partials
     const float* __restrict__ fcw;
     const float* __restrict__ fcb;
-    const float* __restrict__ inv_n;
-    const float* __restrict__ labels;
+    const float* __restrict__ inv_n;   // [n_dst] renumbered
+    const float* __restrict__ labels;  // [n_dst] renumbered
+    const int* __restrict__ perm;      // [n_dst] renumbered -> caller's variable id (where the logit goes)
     float inv_batch;
-    float* __restrict__ logits;        // [n_dst]
+    float* __restrict__ logits;        // [n_dst] caller's order
     float* __restrict__ g_out;         // [n_dst, 16]  dL/dh of the head, already ReLU-masked
     float* __restrict__ head_part;     // [grid, 18]   {dW_fc[16], db_fc, loss} per workgroup
 };
@@ -202,29 +247,26 @@ struct FwdLaunch16 {
     FwdJob16 job[MAXJOBS];
     int n_jobs;
 };
-
 struct FwdW16 {        // per job in LDS: the B operands of the three 16x16 GEMMs, small vectors (read as float4 at 4 part)
     float BPq[256], BWv[256], BWs[256];
     float pq0[16], Pt[16], bv[16], we[16], bs[16], fcw[16];
     float pt0, fcb;
 };
-
 struct SoftState {
     float4 Z;
     float m, L, u;
 };
 
-// the attention sweep of one quad over its nonzeros (first, first + stride, ... < end): online segment softmax
+// the attention sweep of one quad over its nonzeros (first, first + stride, ... < end): online segment softmax.
+// The four lanes of the quad fetch four consecutive entries of the row and share them by DPP; the entries of the
+// next four are in flight while the current four source rows are gathered.
 __device__ __forceinline__ void fwd16_edges(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r,
                                             const float4& qp, float t, int part, SoftState& st) {
-    const int n_mine = r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
+    const int n_mine = slot_count(r);
+    int2 en = part < n_mine ? s.sent[r.first + part * r.stride] : make_int2(0, 0);
     for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        // the four lanes of the quad fetch four consecutive entries of the row and share them by DPP
-        const int km = k0 + part;
-        const bool okm = km < n_mine;
-        const int em = r.first + km * r.stride;
-        const int colm = okm ? s.idx[em] : 0;
-        const float am = okm ? s.val[em] : 0.0f;
+        const int colm = en.x;
+        const float am = __int_as_float(en.y);
         const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
         const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am), a2 = quad_bcast<2>(am), a3 = quad_bcast<3>(am);
         const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
@@ -233,6 +275,8 @@ __device__ __forceinline__ void fwd16_edges(const ItemsDev& s, const float* __re
         if (ok1) x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
         if (ok2) x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
         if (ok3) x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
+        const int kn = k0 + 4 + part;
+        en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
         const float d0 = ok0 ? fmaf(a0, t, quad_sum(dot4(qp, x0))) : NEG_BIG;
         const float d1 = ok1 ? fmaf(a1, t, quad_sum(dot4(qp, x1))) : NEG_BIG;
         const float d2 = ok2 ? fmaf(a2, t, quad_sum(dot4(qp, x2))) : NEG_BIG;
@@ -256,17 +300,17 @@ __device__ __forceinline__ void fwd16_edges(const ItemsDev& s, const float* __re
     }
 }
 
-// all 16 quads of the wavefront hold partial states of ONE row: every lane ends with the row's state
-__device__ __forceinline__ void soft_merge_wave(SoftState& st) {
-    const float M = quads_max<64>(st.m);
+// the units that share a row hold partial states: every lane ends with the row's state
+__device__ __forceinline__ void soft_merge(SoftState& st, int mode) {
+    const float M = shared_max4(st.m, mode);
     const float f = exp_acc(st.m - M);      // partial without nonzeros: exp(-huge) == 0
     st.m = M;
-    st.L = quads_sum<64>(st.L * f);
-    st.u = quads_sum<64>(st.u * f);
-    st.Z.x = quads_sum<64>(st.Z.x * f);
-    st.Z.y = quads_sum<64>(st.Z.y * f);
-    st.Z.z = quads_sum<64>(st.Z.z * f);
-    st.Z.w = quads_sum<64>(st.Z.w * f);
+    st.L = shared_sum4(st.L * f, mode);
+    st.u = shared_sum4(st.u * f, mode);
+    st.Z.x = shared_sum4(st.Z.x * f, mode);
+    st.Z.y = shared_sum4(st.Z.y * f, mode);
+    st.Z.z = shared_sum4(st.Z.z * f, mode);
+    st.Z.w = shared_sum4(st.Z.w * f, mode);
 }
 
 struct HeadAcc {
@@ -292,12 +336,8 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     SoftState st;
     st.Z = f4zero(); st.m = NEG_BIG; st.L = 0.0f; st.u = 0.0f;
     fwd16_edges(J.s, J.x_src, r, qp, t, part, st);
-    bool writer = have;
-    if (r.mode >= 1) {
-        soft_merge_wave(st);
-        writer = (lane >> 2) == 0;
-    }
-    if (r.mode == 2) {       // merge the 16 wavefronts of the workgroup through LDS (fixed order)
+    if (r.mode >= 1) soft_merge(st, r.mode);
+    if (r.mode == 3) {       // merge the 16 wavefronts of the workgroup through LDS (fixed order)
         const int wave = threadIdx.x >> 6;
         if (lane < 4) {
             float* slot = merge_lds + wave * 20;
@@ -317,9 +357,9 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
             fma4(f, lds4(merge_lds + w * 20 + 4 + 4 * part), Z);
         }
         st.m = M; st.L = L; st.u = u; st.Z = Z;
-        writer = threadIdx.x < 4;
         __syncthreads();     // the slots are free for the next block-tier row
     }
+    const bool writer = r.writer;
     // epilogue: o = Wv Zn + Ws x + (bs + S bv + un we)
     const float rinv = 1.0f / (st.L + 1e-16f);   // torch_geometric.utils.softmax: sum + 1e-16
     const float S = st.L * rinv, un = st.u * rinv;
@@ -346,7 +386,7 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     if (J.head) {        // fc (16 -> 1) on the conv's output row, reference linear_program_methods.py:250
         const float4 fw = lds4(W.fcw + 4 * part);
         const float z = quad_sum(dot4(hv, fw)) + W.fcb;
-        if (writer && part == 0) J.logits[r.row] = z;
+        if (writer && part == 0) J.logits[J.perm[r.row]] = z;
         if (J.head == 2 && writer) {      // BCEWithLogitsLoss, mean per instance / batch: linear_program_experiment.py:41,139-140
             const float y = J.labels[r.row];
             const float wn = J.inv_n[r.row] * J.inv_batch;
@@ -362,6 +402,26 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
                 ha.l += wn * (fmaxf(z, 0.0f) - z * y + log1pf(e));
             }
         }
+    }
+}
+
+// {dW_fc[16], db, loss} of the workgroup -> head_part[blockIdx][18] (wave order)
+__device__ __forceinline__ void head_partials_store(HeadAcc& ha, float* head_lds, float* head_part, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    ha.w.x = quads_sum<64>(ha.w.x); ha.w.y = quads_sum<64>(ha.w.y);
+    ha.w.z = quads_sum<64>(ha.w.z); ha.w.w = quads_sum<64>(ha.w.w);
+    ha.b = wave_sum(ha.b);
+    ha.l = wave_sum(ha.l);
+    if (lane < 4) {
+        float* d = head_lds + wave * 18 + 4 * lane;
+        d[0] = ha.w.x; d[1] = ha.w.y; d[2] = ha.w.z; d[3] = ha.w.w;
+    }
+    if (lane == 0) { head_lds[wave * 18 + 16] = ha.b; head_lds[wave * 18 + 17] = ha.l; }
+    __syncthreads();
+    if (tid < 18) {
+        float v = 0.0f;
+        for (int w = 0; w < FW; ++w) v += head_lds[w * 18 + tid];
+        head_part[(size_t)blockIdx.x * 18 + tid] = v;
     }
 }
 
@@ -394,49 +454,34 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
     float* tiles = tiles_ + wave * 3 * TILE;
     HeadAcc ha;
     ha.w = f4zero(); ha.b = 0.0f; ha.l = 0.0f;
-    const int gw = blockIdx.x * FW + wave, nw = gridDim.x * FW;
+    // this workgroup's partition of the instances, its rank among the partition's workgroups, their wavefronts
+    const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
+    const int gw = bi * FW + wave, nw = gp * FW;
     int base = 0;
-    bool any_head = false;
+    float* head_part = nullptr;
     for (int j = 0; j < A.n_jobs; ++j) {
         const FwdJob16& J = A.job[j];
-        any_head |= J.head == 2;
+        const PartTiers P = J.s.part[px];
+        if (J.head == 2) head_part = J.head_part;
         // block tier: the whole workgroup walks one long row at a time (longest rows first)
-        for (int k = blockIdx.x; k < J.s.n_block; k += gridDim.x)
-            fwd16_row(J, Ws_[j], block_slot<4>(J.s, k, tid), part, lane, merge_lds, tiles, ha);
-        // wave loop: the items of all jobs form one sequence dealt round-robin over the wavefronts
-        const int n_items = wave_items16(J.s);
+        for (int k = bi; k < P.n_block; k += gp)
+            fwd16_row(J, Ws_[j], block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds, tiles, ha);
+        // wave loop: the items of all jobs form one sequence dealt round-robin over the partition's wavefronts
+        const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
         for (; it < n_items; it += nw)
-            fwd16_row(J, Ws_[j], item_slot<4>(J.s, it, lane), part, lane, merge_lds, tiles, ha);
+            fwd16_row(J, Ws_[j], item_slot<4>(J.s, P, it, lane), part, lane, merge_lds, tiles, ha);
         base += n_items;
     }
-    // fc partial sums of this workgroup (one job at most has a head)
-    if (!any_head) return;
-    ha.w.x = quads_sum<64>(ha.w.x); ha.w.y = quads_sum<64>(ha.w.y);
-    ha.w.z = quads_sum<64>(ha.w.z); ha.w.w = quads_sum<64>(ha.w.w);
-    ha.b = wave_sum(ha.b);
-    ha.l = wave_sum(ha.l);
-    if (lane < 4) {
-        float* d = head_lds + wave * 18 + 4 * lane;
-        d[0] = ha.w.x; d[1] = ha.w.y; d[2] = ha.w.z; d[3] = ha.w.w;
-    }
-    if (lane == 0) { head_lds[wave * 18 + 16] = ha.b; head_lds[wave * 18 + 17] = ha.l; }
-    __syncthreads();
-    if (tid < 18) {
-        float v = 0.0f;
-        for (int w = 0; w < FW; ++w) v += head_lds[w * 18 + tid];
-        for (int j = 0; j < A.n_jobs; ++j)
-            if (A.job[j].head == 2) A.job[j].head_part[(size_t)blockIdx.x * 18 + tid] = v;
-    }
+    if (head_part) head_partials_store(ha, head_lds, head_part, tid);     // (uniform: one job at most has a head)
 }
 
 // ====================================================================================================
-// forward, 1 source channel (layer 1): one lane per row
+// forward, 1 source channel (layer 1): one lane per row; the source feature rides with the value
 // ====================================================================================================
 struct FwdJob1 {
     ItemsDev s;
-    const float* __restrict__ x_src;   // [n_src]
-    const float* __restrict__ x_dst;   // [n_dst]
+    const float* __restrict__ x_dst;   // [n_dst] renumbered
     const float* __restrict__ D;
     ConvParams p;
     float* __restrict__ h;             // [n_dst, 16]
@@ -455,18 +500,22 @@ struct Soft1 {
     float m, L, u, Z;
 };
 
-__device__ __forceinline__ void fwd1_edges(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r, float qp,
-                                           float t, Soft1& st) {
-    const int n_mine = r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine;
-        const int e0 = r.first + k0 * r.stride, e1 = e0 + r.stride;
-        const int c0 = ok0 ? s.idx[e0] : 0, c1 = ok1 ? s.idx[e1] : 0;
-        const float a0 = ok0 ? s.val[e0] : 0.0f, a1 = ok1 ? s.val[e1] : 0.0f;
-        const float x0 = ok0 ? X[c0] : 0.0f, x1 = ok1 ? X[c1] : 0.0f;
-        const float d0 = ok0 ? fmaf(qp, x0, a0 * t) : NEG_BIG;
-        const float d1 = ok1 ? fmaf(qp, x1, a1 * t) : NEG_BIG;
-        const float mi = fmaxf(d0, d1);
+__device__ __forceinline__ void fwd1_edges(const ItemsDev& s, const RowSlot& r, float qp, float t, Soft1& st) {
+    const int n_mine = slot_count(r);
+    const float2 z2 = make_float2(0.0f, 0.0f);
+    float2 n0 = 0 < n_mine ? s.sax[r.first] : z2, n1 = 1 < n_mine ? s.sax[r.first + r.stride] : z2;
+    float2 n2 = 2 < n_mine ? s.sax[r.first + 2 * r.stride] : z2, n3 = 3 < n_mine ? s.sax[r.first + 3 * r.stride] : z2;
+    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
+        const float2 e0 = n0, e1 = n1, e2 = n2, e3 = n3;
+        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
+        const int eb = r.first + (k0 + 4) * r.stride;
+        n0 = k0 + 4 < n_mine ? s.sax[eb] : z2;
+        n1 = k0 + 5 < n_mine ? s.sax[eb + r.stride] : z2;
+        n2 = k0 + 6 < n_mine ? s.sax[eb + 2 * r.stride] : z2;
+        n3 = k0 + 7 < n_mine ? s.sax[eb + 3 * r.stride] : z2;
+        const float d0 = ok0 ? fmaf(qp, e0.y, e0.x * t) : NEG_BIG, d1 = ok1 ? fmaf(qp, e1.y, e1.x * t) : NEG_BIG;
+        const float d2 = ok2 ? fmaf(qp, e2.y, e2.x * t) : NEG_BIG, d3 = ok3 ? fmaf(qp, e3.y, e3.x * t) : NEG_BIG;
+        const float mi = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
         if (__any(mi > st.m)) {
             const float mn = fmaxf(st.m, mi);
             const float sc = exp_acc(st.m - mn);
@@ -474,18 +523,11 @@ __device__ __forceinline__ void fwd1_edges(const ItemsDev& s, const float* __res
             st.m = mn;
         }
         const float p0 = ok0 ? exp_acc(d0 - st.m) : 0.0f, p1 = ok1 ? exp_acc(d1 - st.m) : 0.0f;
-        st.L += p0 + p1;
-        st.u = fmaf(p0, a0, fmaf(p1, a1, st.u));
-        st.Z = fmaf(p0, x0, fmaf(p1, x1, st.Z));
+        const float p2 = ok2 ? exp_acc(d2 - st.m) : 0.0f, p3 = ok3 ? exp_acc(d3 - st.m) : 0.0f;
+        st.L += (p0 + p1) + (p2 + p3);
+        st.u = fmaf(p0, e0.x, fmaf(p1, e1.x, fmaf(p2, e2.x, fmaf(p3, e3.x, st.u))));
+        st.Z = fmaf(p0, e0.y, fmaf(p1, e1.y, fmaf(p2, e2.y, fmaf(p3, e3.y, st.Z))));
     }
-}
-__device__ __forceinline__ void soft1_merge_wave(Soft1& st) {
-    const float M = group_max<64>(st.m);
-    const float f = exp_acc(st.m - M);
-    st.m = M;
-    st.L = wave_sum(st.L * f);
-    st.u = wave_sum(st.u * f);
-    st.Z = wave_sum(st.Z * f);
 }
 
 __device__ __forceinline__ void fwd1_row(const FwdJob1& J, const FwdW1& W, const RowSlot& r, int lane, float* merge_lds) {
@@ -494,13 +536,16 @@ __device__ __forceinline__ void fwd1_row(const FwdJob1& J, const FwdW1& W, const
     const float qp = fmaf(W.pq, x, W.pq0), t = fmaf(W.pt, x, W.pt0);
     Soft1 st;
     st.m = NEG_BIG; st.L = 0.0f; st.u = 0.0f; st.Z = 0.0f;
-    fwd1_edges(J.s, J.x_src, r, qp, t, st);
-    bool writer = have;
+    fwd1_edges(J.s, r, qp, t, st);
     if (r.mode >= 1) {
-        soft1_merge_wave(st);
-        writer = lane == 0;
+        const float M = shared_max1(st.m, r.mode);
+        const float f = exp_acc(st.m - M);
+        st.m = M;
+        st.L = shared_sum1(st.L * f, r.mode);
+        st.u = shared_sum1(st.u * f, r.mode);
+        st.Z = shared_sum1(st.Z * f, r.mode);
     }
-    if (r.mode == 2) {
+    if (r.mode == 3) {
         const int wave = threadIdx.x >> 6;
         if (lane == 0) *reinterpret_cast<float4*>(merge_lds + wave * 4) = make_float4(st.m, st.L, st.u, st.Z);
         __syncthreads();
@@ -515,10 +560,9 @@ __device__ __forceinline__ void fwd1_row(const FwdJob1& J, const FwdW1& W, const
             Z = fmaf(f, hd.w, Z);
         }
         st.m = M; st.L = L; st.u = u; st.Z = Z;
-        writer = threadIdx.x == 0;
         __syncthreads();
     }
-    if (!writer) return;
+    if (!r.writer) return;
     const float rinv = 1.0f / (st.L + 1e-16f);
     const float S = st.L * rinv, un = st.u * rinv, zn = st.Z * rinv;
     float o[16];
@@ -556,18 +600,17 @@ __global__ __launch_bounds__(FT) void fused_fwd1_kernel(FwdLaunch1 A) {
         }
     }
     __syncthreads();
-    for (int j = 0; j < A.n_jobs; ++j) {
-        const FwdJob1& J = A.job[j];
-        for (int k = blockIdx.x; k < J.s.n_block; k += gridDim.x)
-            fwd1_row(J, Ws_[j], block_slot<1>(J.s, k, tid), lane, merge_lds);
-    }
-    const int gw = blockIdx.x * FW + wave, nw = gridDim.x * FW;
+    const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
+    const int gw = bi * FW + wave, nw = gp * FW;
     int base = 0;
     for (int j = 0; j < A.n_jobs; ++j) {
         const FwdJob1& J = A.job[j];
-        const int n_items = wave_items64(J.s);
+        const PartTiers P = J.s.part[px];
+        for (int k = bi; k < P.n_block; k += gp)
+            fwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds);
+        const int n_items = wave_items<1>(P);
         int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) fwd1_row(J, Ws_[j], item_slot<1>(J.s, it, lane), lane, merge_lds);
+        for (; it < n_items; it += nw) fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
         base += n_items;
     }
 }
@@ -612,13 +655,11 @@ struct BwdState {
 __device__ __forceinline__ void bwd16_edges(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r,
                                             const float4& qp, const float4& gv, float t, float m, float rinv, float ge,
                                             float cc, int part, BwdState& st) {
-    const int n_mine = r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
+    const int n_mine = slot_count(r);
+    int2 en = part < n_mine ? s.sent[r.first + part * r.stride] : make_int2(0, 0);
     for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        const int km = k0 + part;
-        const bool okm = km < n_mine;
-        const int em = r.first + km * r.stride;
-        const int colm = okm ? s.idx[em] : 0;
-        const float am = okm ? s.val[em] : 0.0f;
+        const int colm = en.x;
+        const float am = __int_as_float(en.y);
         const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
         const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am), a2 = quad_bcast<2>(am), a3 = quad_bcast<3>(am);
         const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
@@ -627,6 +668,8 @@ __device__ __forceinline__ void bwd16_edges(const ItemsDev& s, const float* __re
         if (ok1) x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
         if (ok2) x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
         if (ok3) x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
+        const int kn = k0 + 4 + part;
+        en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
 #define MLLP_BWD_SLOT(OK, A_, X_)                                                          \
     {                                                                                      \
         const float l_ = fmaf(A_, t, quad_sum(dot4(qp, X_)));                              \
@@ -650,11 +693,9 @@ constexpr int TB_G = 0, TB_X = 1, TB_Z = 2, TB_DQ = 3, TB_SC = 4, TB_E = 5, TB_N
 __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, int part,
                                           int lane, float* merge_lds, float* tiles, f32x4m (&acc)[STAT_TILES]) {
     const bool have = r.row >= 0;
+    const bool writer = r.writer;
     float4 qp, gv;
     float t, m, rinv, ge, cc;
-    bool writer = have;
-    if (r.mode >= 1) writer = (lane >> 2) == 0;
-    if (r.mode == 2) writer = threadIdx.x < 4;
     {   // everything of the row that the sweep does not need stays in the tiles G, X, Z, E until the statistics
         const size_t ro = have ? (size_t)r.row * 16 + 4 * part : 0;
         float4 g = have ? ld4(J.dh_a + ro) : f4zero();
@@ -696,12 +737,12 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
     st.dq = f4zero(); st.ds = 0.0f; st.dt = 0.0f;
     bwd16_edges(J.s, J.x_src, r, qp, gv, t, m, rinv, ge, cc, part, st);
     if (r.mode >= 1) {
-        st.ds = quads_sum<64>(st.ds);
-        st.dt = quads_sum<64>(st.dt);
-        st.dq.x = quads_sum<64>(st.dq.x); st.dq.y = quads_sum<64>(st.dq.y);
-        st.dq.z = quads_sum<64>(st.dq.z); st.dq.w = quads_sum<64>(st.dq.w);
+        st.ds = shared_sum4(st.ds, r.mode);
+        st.dt = shared_sum4(st.dt, r.mode);
+        st.dq.x = shared_sum4(st.dq.x, r.mode); st.dq.y = shared_sum4(st.dq.y, r.mode);
+        st.dq.z = shared_sum4(st.dq.z, r.mode); st.dq.w = shared_sum4(st.dq.w, r.mode);
     }
-    if (r.mode == 2) {
+    if (r.mode == 3) {
         const int wave = threadIdx.x >> 6;
         if (lane < 4) {
             float* slot = merge_lds + wave * 20;
@@ -733,7 +774,7 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         if (writer) *reinterpret_cast<float4*>(J.dx_dst + (size_t)r.row * 16 + 4 * part) = v;
     }
     // statistics (node_kernels.hip::param_stats16_kernel): operands with m / n = channel, k = row.  A row shared by
-    // the wavefront (workgroup) is counted once: only quad 0 keeps it, the other 15 rows of the tiles become zeros
+    // several quads is counted once: only its writer keeps it, the other rows of the tiles become zeros
     if (r.mode >= 1 && !writer) {
         const float4 z4 = f4zero();
         tile_put(tiles + TB_G * TILE, z4, lane);
@@ -785,19 +826,21 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
     }
     __syncthreads();
     float* tiles = tiles_ + wave * TB_N * TILE;
-    const int gw = blockIdx.x * FW + wave, nw = gridDim.x * FW;
+    const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
+    const int gw = bi * FW + wave, nw = gp * FW;
     int base = 0;
     for (int j = 0; j < A.n_jobs; ++j) {
         const BwdJob16& J = A.job[j];
+        const PartTiers P = J.s.part[px];
         f32x4m acc[STAT_TILES];
 #pragma unroll
         for (int i = 0; i < STAT_TILES; ++i) acc[i] = splat4(0.0f);
-        for (int k = blockIdx.x; k < J.s.n_block; k += gridDim.x)
-            bwd16_row(J, Ws_[j], block_slot<4>(J.s, k, tid), part, lane, merge_lds, tiles, acc);
-        const int n_items = wave_items16(J.s);
+        for (int k = bi; k < P.n_block; k += gp)
+            bwd16_row(J, Ws_[j], block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds, tiles, acc);
+        const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
         for (; it < n_items; it += nw)
-            bwd16_row(J, Ws_[j], item_slot<4>(J.s, it, lane), part, lane, merge_lds, tiles, acc);
+            bwd16_row(J, Ws_[j], item_slot<4>(J.s, P, it, lane), part, lane, merge_lds, tiles, acc);
         base += n_items;
         // the workgroup's partial statistics: the 16 wavefronts' tiles summed in wave order, one tile at a time
         __syncthreads();
@@ -827,18 +870,20 @@ struct SrcJob16 {
     const float* __restrict__ rec;     // [n_cols, REC_W]
     float* __restrict__ dx;            // [n_rows, 16]
 };
+struct SrcLaunch16 {
+    SrcJob16 job[MAXJOBS];
+    int n_jobs;
+};
 
 __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, int part, int lane, float* merge_lds) {
     const bool have = r.row >= 0;
     const float4 xj = have ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
     float4 acc = f4zero();
-    const int n_mine = r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
+    const int n_mine = slot_count(r);
+    int2 en = (part & 1) < n_mine ? J.s.sent[r.first + (part & 1) * r.stride] : make_int2(0, 0);
     for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
-        const int km = k0 + (part & 1);
-        const bool okm = km < n_mine;
-        const int em = r.first + km * r.stride;
-        const int colm = okm ? J.s.idx[em] : 0;
-        const float am = okm ? J.s.val[em] : 0.0f;
+        const int colm = en.x;
+        const float am = __int_as_float(en.y);
         const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm);
         const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am);
         const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine;
@@ -852,6 +897,8 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, i
             const float* rr = J.rec + (size_t)c1 * REC_W;
             q1 = ld4(rr + 4 * part); g1 = ld4(rr + 16 + 4 * part); s1 = ld4(rr + 32); cc1 = rr[36];
         }
+        const int kn = k0 + 2 + (part & 1);
+        en = kn < n_mine ? J.s.sent[r.first + kn * r.stride] : make_int2(0, 0);
         {
             const float l = fmaf(a0, s0.x, quad_sum(dot4(q0, xj)));
             const float al = ok0 ? exp_acc(l - s0.y) * s0.z : 0.0f;
@@ -867,33 +914,48 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, i
             fma4(dl, q1, acc);
         }
     }
-    bool writer = have;
     if (r.mode >= 1) {
-        acc.x = quads_sum<64>(acc.x); acc.y = quads_sum<64>(acc.y);
-        acc.z = quads_sum<64>(acc.z); acc.w = quads_sum<64>(acc.w);
-        writer = (lane >> 2) == 0;
+        acc.x = shared_sum4(acc.x, r.mode); acc.y = shared_sum4(acc.y, r.mode);
+        acc.z = shared_sum4(acc.z, r.mode); acc.w = shared_sum4(acc.w, r.mode);
     }
-    if (r.mode == 2) {
+    if (r.mode == 3) {
         const int wave = threadIdx.x >> 6;
         if (lane < 4) *reinterpret_cast<float4*>(merge_lds + wave * 20 + 4 * part) = acc;
         __syncthreads();
         float4 v = f4zero();
         for (int w = 0; w < FW; ++w) v = f4add(v, lds4(merge_lds + w * 20 + 4 * part));
         acc = v;
-        writer = threadIdx.x < 4;
         __syncthreads();
     }
-    if (writer) *reinterpret_cast<float4*>(J.dx + (size_t)r.row * 16 + 4 * part) = acc;
+    if (r.writer) *reinterpret_cast<float4*>(J.dx + (size_t)r.row * 16 + 4 * part) = acc;
+}
+
+__global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
+    __shared__ float merge_lds[FW * 20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, part = lane & 3;
+    const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
+    const int gw = bi * FW + wave, nw = gp * FW;
+    int base = 0;
+    for (int j = 0; j < A.n_jobs; ++j) {
+        const SrcJob16& J = A.job[j];
+        const PartTiers P = J.s.part[px];
+        for (int k = bi; k < P.n_block; k += gp)
+            src16_row(J, block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds);
+        const int n_items = wave_items<4>(P);
+        int it = (gw - base % nw + nw) % nw;
+        for (; it < n_items; it += nw) src16_row(J, item_slot<4>(J.s, P, it, lane), part, lane, merge_lds);
+        base += n_items;
+    }
 }
 
 // ====================================================================================================
 // backward, destination-major, 1 channel (layer 1: inputs are data, no input gradients): one lane per row
-//   statistics in the layout of node_kernels.hip::param_stats1_kernel
+//   statistics in the layout of node_kernels.hip::param_stats1_kernel: T[o][n] = sum_rows g_o R_n with
+//   R = {x, Z, 1, S, u} on the MFMA (the wavefront's 64 rows through two LDS tiles), six scalar sums on the VALU
 // ====================================================================================================
 struct BwdJob1 {
     ItemsDev s;
-    const float* __restrict__ x_src;   // [n_src]
-    const float* __restrict__ x_dst;   // [n_dst]
+    const float* __restrict__ x_dst;   // [n_dst] renumbered
     const float* __restrict__ D;
     ConvParams p;
     const float* __restrict__ h;       // [n_dst, 16]
@@ -903,21 +965,21 @@ struct BwdJob1 {
     const float* __restrict__ aux;     // [n_dst, 4]
     float* __restrict__ stats;         // [grid, STAT_FLOATS]
 };
+struct BwdLaunch1 {
+    BwdJob1 job[MAXJOBS];
+    int n_jobs;
+};
 struct BwdW1 {
     float wv[16], bv[16], we[16];
     float pq, pq0, pt, pt0;
 };
-// statistics of a scalar conv: T[o][n] = sum_rows g_o R_n with R = {x, Z, 1, S, u} on the MFMA (the wavefront's 64
-// rows through two LDS tiles), and six scalar sums on the VALU
 constexpr int G1S = 17, R1S = 9;                       // row strides of the g tile (16 channels) and the R tile (5 columns)
 constexpr int TILE1 = 64 * G1S + 64 * R1S;             // floats per wavefront
 
 __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const RowSlot& r, int lane, float* merge_lds,
                                          float* tiles, f32x4m& accT, float (&accS)[6]) {
     const bool have = r.row >= 0;
-    bool writer = have;
-    if (r.mode >= 1) writer = lane == 0;
-    if (r.mode == 2) writer = threadIdx.x == 0;
+    const bool writer = r.writer;
     float gv = 0.0f, ge = 0.0f, gb = 0.0f;
     {   // g = (dh_a + dh_b) * (h > 0); the row of g goes to the tile (zeros unless this lane owns the row)
         const size_t ro = (size_t)(have ? r.row : 0) * 16;
@@ -956,24 +1018,37 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
     const float cc = gb - Dn;
     const float qp = fmaf(W.pq, x, W.pq0), t = fmaf(W.pt, x, W.pt0);
     float ds = 0.0f, dt = 0.0f, dq = 0.0f;
-    const int n_mine = r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine;
-        const int e0 = r.first + k0 * r.stride, e1 = e0 + r.stride;
-        const int c0 = ok0 ? J.s.idx[e0] : 0, c1 = ok1 ? J.s.idx[e1] : 0;
-        const float a0 = ok0 ? J.s.val[e0] : 0.0f, a1 = ok1 ? J.s.val[e1] : 0.0f;
-        const float x0 = ok0 ? J.x_src[c0] : 0.0f, x1 = ok1 ? J.x_src[c1] : 0.0f;
-        const float l0 = fmaf(qp, x0, a0 * t), l1 = fmaf(qp, x1, a1 * t);
-        const float al0 = ok0 ? exp_acc(l0 - ax.y) * ax.z : 0.0f, al1 = ok1 ? exp_acc(l1 - ax.y) * ax.z : 0.0f;
-        const float dl0 = al0 * fmaf(gv, x0, fmaf(a0, ge, cc)), dl1 = al1 * fmaf(gv, x1, fmaf(a1, ge, cc));
-        ds += dl0 + dl1;
-        dt = fmaf(dl0, a0, fmaf(dl1, a1, dt));
-        dq = fmaf(dl0, x0, fmaf(dl1, x1, dq));
+    const int n_mine = slot_count(r);
+    const float2 z2 = make_float2(0.0f, 0.0f);
+    float2 n0 = 0 < n_mine ? J.s.sax[r.first] : z2, n1 = 1 < n_mine ? J.s.sax[r.first + r.stride] : z2;
+    float2 n2 = 2 < n_mine ? J.s.sax[r.first + 2 * r.stride] : z2, n3 = 3 < n_mine ? J.s.sax[r.first + 3 * r.stride] : z2;
+    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
+        const float2 e0 = n0, e1 = n1, e2 = n2, e3 = n3;
+        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
+        const int eb = r.first + (k0 + 4) * r.stride;
+        n0 = k0 + 4 < n_mine ? J.s.sax[eb] : z2;
+        n1 = k0 + 5 < n_mine ? J.s.sax[eb + r.stride] : z2;
+        n2 = k0 + 6 < n_mine ? J.s.sax[eb + 2 * r.stride] : z2;
+        n3 = k0 + 7 < n_mine ? J.s.sax[eb + 3 * r.stride] : z2;
+#define MLLP_BWD1_SLOT(OK, E_)                                                             \
+    {                                                                                      \
+        const float l_ = fmaf(qp, E_.y, E_.x * t);                                         \
+        const float al_ = OK ? exp_acc(l_ - ax.y) * ax.z : 0.0f;                           \
+        const float dl_ = al_ * fmaf(gv, E_.y, fmaf(E_.x, ge, cc));                        \
+        ds += dl_;                                                                         \
+        dt = fmaf(dl_, E_.x, dt);                                                          \
+        dq = fmaf(dl_, E_.y, dq);                                                          \
+    }
+        MLLP_BWD1_SLOT(ok0, e0)
+        MLLP_BWD1_SLOT(ok1, e1)
+        MLLP_BWD1_SLOT(ok2, e2)
+        MLLP_BWD1_SLOT(ok3, e3)
+#undef MLLP_BWD1_SLOT
     }
     if (r.mode >= 1) {
-        ds = wave_sum(ds); dt = wave_sum(dt); dq = wave_sum(dq);
+        ds = shared_sum1(ds, r.mode); dt = shared_sum1(dt, r.mode); dq = shared_sum1(dq, r.mode);
     }
-    if (r.mode == 2) {
+    if (r.mode == 3) {
         const int wave = threadIdx.x >> 6;
         if (lane == 0) *reinterpret_cast<float4*>(merge_lds + wave * 4) = make_float4(ds, dt, dq, 0.0f);
         __syncthreads();
@@ -1006,17 +1081,6 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
     }
 }
 
-// ---- one launch of the backward chain: up to two destination-major jobs (16- or 1-channel) and up to two
-//      source-major jobs; all of them only read what earlier launches wrote --------------------------------------
-struct BwdLaunch1 {
-    BwdJob1 job[MAXJOBS];
-    int n_jobs;
-};
-struct SrcLaunch16 {
-    SrcJob16 job[MAXJOBS];
-    int n_jobs;
-};
-
 __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
     __shared__ BwdW1 Ws_[MAXJOBS];
     __shared__ float merge_lds[FW * 4];
@@ -1030,17 +1094,19 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
     }
     __syncthreads();
     float* tiles = tiles_ + wave * TILE1;
-    const int gw = blockIdx.x * FW + wave, nw = gridDim.x * FW;
+    const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
+    const int gw = bi * FW + wave, nw = gp * FW;
     int base = 0;
     for (int j = 0; j < A.n_jobs; ++j) {
         const BwdJob1& J = A.job[j];
+        const PartTiers P = J.s.part[px];
         f32x4m accT = splat4(0.0f);
         float accS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int k = blockIdx.x; k < J.s.n_block; k += gridDim.x)
-            bwd1_row(J, Ws_[j], block_slot<1>(J.s, k, tid), lane, merge_lds, tiles, accT, accS);
-        const int n_items = wave_items64(J.s);
+        for (int k = bi; k < P.n_block; k += gp)
+            bwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds, tiles, accT, accS);
+        const int n_items = wave_items<1>(P);
         int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) bwd1_row(J, Ws_[j], item_slot<1>(J.s, it, lane), lane, merge_lds, tiles, accT, accS);
+        for (; it < n_items; it += nw) bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
         base += n_items;
         // wavefronts -> workgroup (LDS, wave order), one partial per workgroup in the layout of param_stats1_kernel
         __syncthreads();
@@ -1072,52 +1138,61 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
     }
 }
 
-__global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
-    __shared__ float merge_lds[FW * 20];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, part = lane & 3;
-    for (int j = 0; j < A.n_jobs; ++j) {
-        const SrcJob16& J = A.job[j];
-        for (int k = blockIdx.x; k < J.s.n_block; k += gridDim.x)
-            src16_row(J, block_slot<4>(J.s, k, tid), part, lane, merge_lds);
+// ====================================================================================================
+// head backward from given dL/dlogits (caller's variable order): dh3 = dz w_fc (unmasked), fc gradient partials
+// ====================================================================================================
+__global__ __launch_bounds__(FT) void fused_head_bwd_kernel(int n, const float* __restrict__ h3, const float* __restrict__ fcw,
+                                                            const float* __restrict__ dlogits, const int* __restrict__ perm,
+                                                            float* __restrict__ dh3, float* __restrict__ head_part) {
+    __shared__ float head_lds[FW * 18];
+    const int tid = threadIdx.x, lane = tid & 63, part = lane & 3;
+    HeadAcc ha;
+    ha.w = f4zero(); ha.b = 0.0f; ha.l = 0.0f;
+    const float4 fw = ld4(fcw + 4 * part);
+    for (int row = blockIdx.x * (FT / 4) + (tid >> 2); row < n; row += gridDim.x * (FT / 4)) {
+        const float dz = dlogits[perm[row]];
+        const float4 hv = ld4(h3 + (size_t)row * 16 + 4 * part);
+        *reinterpret_cast<float4*>(dh3 + (size_t)row * 16 + 4 * part) = f4scale(fw, dz);
+        fma4(dz, hv, ha.w);
+        if (part == 0) ha.b += dz;
     }
-    const int gw = blockIdx.x * FW + wave, nw = gridDim.x * FW;
-    int base = 0;
-    for (int j = 0; j < A.n_jobs; ++j) {
-        const SrcJob16& J = A.job[j];
-        const int n_items = wave_items16(J.s);
-        int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) src16_row(J, item_slot<4>(J.s, it, lane), part, lane, merge_lds);
-        base += n_items;
-    }
+    head_partials_store(ha, head_lds, head_part, tid);
 }
 
 // ====================================================================================================
-// reduction of the per-workgroup statistics partials: out[c][i] = sum_b stats_c[b][i], fixed order.
-// grid = (convs x 7 tiles); 1024 threads = 4 slices of the partials x 256 columns
+// reduction of the per-workgroup partials: out[c][i] = sum_b stats_c[b][i], fixed order.
+// grid = convs x 7 tiles (1024 threads = 4 slices of the partials x 256 columns) + one workgroup for the fc partials
 // ====================================================================================================
 struct ReduceArgs {
     const float* stats[MODEL_CONVS];
     float* out[MODEL_CONVS];
     int nblk;
-    // the fc partials ride along: workgroup (n_conv * 7) sums head_part[nblk][18] into head_out[18]
-    const float* head_part;
-    float* head_out;     // [17] gradient of fc, then the loss
-    float* loss_out;     // nullable
+    const float* head_part;   // [nblk][18] or nullptr
+    float* head_out;          // [17] gradient of fc
+    float* loss_out;          // nullable
 };
 
 __global__ __launch_bounds__(FT) void fused_reduce_kernel(ReduceArgs A, int n_conv) {
-    __shared__ float sh[4][256];
-    const int tid = threadIdx.x, col = tid & 255, slice = tid >> 8;
-    if ((int)blockIdx.x == n_conv * STAT_TILES) {     // fc partials
+    __shared__ float sh[32][32];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == n_conv * STAT_TILES) {     // fc partials: 32 slices x 18 columns
+        if (!A.head_part) return;
+        const int col = tid & 31, slice = tid >> 5;
         float v = 0.0f;
-        if (slice == 0 && col < 18 && A.head_part)
-            for (int b = 0; b < A.nblk; ++b) v += A.head_part[(size_t)b * 18 + col];
-        if (slice == 0 && col < 18 && A.head_part) {
-            if (col < 17) A.head_out[col] = v;
-            else if (A.loss_out) A.loss_out[0] = v;
+        if (col < 18)
+            for (int b = slice; b < A.nblk; b += 32) v += A.head_part[(size_t)b * 18 + col];
+        sh[slice][col] = v;
+        __syncthreads();
+        if (tid < 18) {
+            float t = 0.0f;
+            for (int q = 0; q < 32; ++q) t += sh[q][tid];
+            if (tid < 17) A.head_out[tid] = t;
+            else if (A.loss_out) A.loss_out[0] = t;
         }
         return;
     }
+    float* sh4 = &sh[0][0];       // [4][256]
+    const int col = tid & 255, slice = tid >> 8;
     const int c = blockIdx.x / STAT_TILES, tile = blockIdx.x % STAT_TILES;
     const float* src = A.stats[c] + tile * 256 + col;
     float v = 0.0f;
@@ -1130,42 +1205,160 @@ __global__ __launch_bounds__(FT) void fused_reduce_kernel(ReduceArgs A, int n_co
         for (int q = 0; q < 8; ++q) v += t[q];
     }
     for (; b < A.nblk; b += 4) v += src[(size_t)b * STAT_FLOATS];
-    sh[slice][col] = v;
+    sh4[slice * 256 + col] = v;
     __syncthreads();
-    if (tid < 256) A.out[c][tile * 256 + tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+    if (tid < 256) A.out[c][tile * 256 + tid] = (sh4[tid] + sh4[256 + tid]) + (sh4[512 + tid] + sh4[768 + tid]);
 }
 
 // ====================================================================================================
-// host side: the whole model on the fused path
+// building the renumbered graph, binding inputs
 // ====================================================================================================
+// one wavefront per renumbered row k: entries of the original row perm[k], source ids renumbered
+__global__ __launch_bounds__(256) void fused_fill_kernel(int n_dst, const int* __restrict__ perm, const int* __restrict__ ptr,
+                                                         const int* __restrict__ idx, const float* __restrict__ val,
+                                                         const int* __restrict__ inv_src, const int* __restrict__ sptr,
+                                                         int2* __restrict__ sent) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n_dst) return;
+    const int r = perm[k], beg = ptr[r], deg = ptr[r + 1] - beg, o = sptr[k];
+    for (int e = lane; e < deg; e += 64) sent[o + e] = make_int2(inv_src[idx[beg + e]], __float_as_int(val[beg + e]));
+}
+__global__ void fused_permute_kernel(int n, const int* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+// sax[e] = {a_e, x_src[source of e]}: layer 1's per-nonzero source feature beside the value
+__global__ void fused_pregather_kernel(int64_t nnz, const int2* __restrict__ sent, const float* __restrict__ xs,
+                                       float2* __restrict__ sax) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int2 v = sent[e];
+        sax[e] = make_float2(__int_as_float(v.y), xs[v.x]);
+    }
+}
+
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, what);
 }
 
-int fused_grid(const mllp_graph* g) { return std::min(std::max(g->n_cu, 1), STAT_BLOCKS_MAX); }
+template <class T>
+static int dev_alloc(mllp_graph* g, size_t count, T** out, const T* host = nullptr) {
+    void* p = nullptr;
+    MLLP_HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    g->allocs.push_back(p);
+    if (host && count) MLLP_HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<T*>(p);
+    return MLLP_OK;
+}
 
-static FwdJob16 fwd_job16(const Orient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
+static void set_tiers(FusedTiersDev& d, const FusedTiers& t) {
+    d.n_block = t.n_block; d.n_wave = t.n_wave; d.n_group = t.n_group; d.n_base = t.n_base;
+}
+
+int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr) {
+    if (g->fused_built) return MLLP_OK;
+    if ((int64_t)g->h_csr_ptr.size() != g->M + 1 && !h_csr_ptr) return fail(MLLP_EINVAL, "fused path: no host row pointers");
+    HostFusedOrient hc, hv;
+    {
+        std::vector<int64_t> inst_nnz((size_t)g->n_inst);
+        for (int64_t k = 0; k < g->n_inst; ++k)
+            inst_nnz[(size_t)k] = (int64_t)h_csr_ptr[g->h_inst_ptr_m[k + 1]] - h_csr_ptr[g->h_inst_ptr_m[k]];
+        const std::vector<int> part = host_partition_instances(inst_nnz, FUSED_PARTS);
+        host_build_fused_orient(h_csr_ptr, (int)g->M, g->h_inst_ptr_m, part, &hc);     // constraints by (partition, row length)
+        host_build_fused_orient(h_csc_ptr, (int)g->N, g->h_inst_ptr_n, part, &hv);     // variables by (partition, column length)
+    }
+    int rc;
+    if ((rc = dev_alloc(g, (size_t)g->M, &g->perm_c, hc.perm.data()))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N, &g->perm_v, hv.perm.data()))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->M, &g->inv_c, hc.inv.data()))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N, &g->inv_v, hv.inv.data()))) return rc;
+    FusedOrient& A = g->FA;
+    FusedOrient& At = g->FAt;
+    A.n_dst = (int)g->M; A.n_src = (int)g->N;
+    At.n_dst = (int)g->N; At.n_src = (int)g->M;
+    for (int q = 0; q < NP; ++q) {
+        set_tiers(A.t16[q], hc.t16[q]); set_tiers(A.t1[q], hc.t1[q]);
+        set_tiers(At.t16[q], hv.t16[q]); set_tiers(At.t1[q], hv.t1[q]);
+    }
+    for (int q = 0; q <= NP; ++q) { A.row0[q] = hc.row0[q]; At.row0[q] = hv.row0[q]; }
+    if ((rc = dev_alloc(g, (size_t)g->M + 1, &A.sptr, hc.sptr.data()))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N + 1, &At.sptr, hv.sptr.data()))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->nnz * 2, &A.sent))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->nnz * 2, &At.sent))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->nnz * 2, &A.sax))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->nnz * 2, &At.sax))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N, &g->inv_n_p))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N, &g->x1_p))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->M, &g->x2_p))) return rc;
+    if ((rc = dev_alloc(g, (size_t)g->N, &g->labels_p))) return rc;
+    if (g->M > 0) {
+        hipLaunchKernelGGL(fused_fill_kernel, dim3((unsigned)((g->M + 3) / 4)), dim3(256), 0, 0, (int)g->M, g->perm_c, g->A.ptr,
+                           g->A.idx, g->A.val, g->inv_v, A.sptr, reinterpret_cast<int2*>(A.sent));
+        if ((rc = check_launch("fused_fill A"))) return rc;
+    }
+    if (g->N > 0) {
+        hipLaunchKernelGGL(fused_fill_kernel, dim3((unsigned)((g->N + 3) / 4)), dim3(256), 0, 0, (int)g->N, g->perm_v, g->At.ptr,
+                           g->At.idx, g->At.val, g->inv_c, At.sptr, reinterpret_cast<int2*>(At.sent));
+        if ((rc = check_launch("fused_fill At"))) return rc;
+        hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, 0, (int)g->N, g->perm_v, g->inv_n, g->inv_n_p);
+        if ((rc = check_launch("fused_permute inv_n"))) return rc;
+    }
+    MLLP_HIP_TRY(hipDeviceSynchronize());
+    g->fused_built = true;
+    return MLLP_OK;
+}
+
+// renumbered copies of the inputs, made when the caller's pointers change (the contents are taken as constant while
+// the pointers are: the model's inputs are data -- reference linear_program_methods.py:90-91)
+static int fused_bind(mllp_graph* g, const float* x1, const float* x2, const float* labels, hipStream_t s) {
+    int rc;
+    if (x1 != g->bound_x1 || x2 != g->bound_x2) {
+        if (g->N > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->N, g->perm_v, x1, g->x1_p);
+        if (g->M > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->M, g->perm_c, x2, g->x2_p);
+        if (g->nnz > 0) {
+            // FA: rows = constraints, sources = variables (x1); FAt: rows = variables, sources = constraints (x2)
+            hipLaunchKernelGGL(fused_pregather_kernel, dim3(1024), dim3(256), 0, s, g->nnz,
+                               reinterpret_cast<const int2*>(g->FA.sent), g->x1_p, reinterpret_cast<float2*>(g->FA.sax));
+            hipLaunchKernelGGL(fused_pregather_kernel, dim3(1024), dim3(256), 0, s, g->nnz,
+                               reinterpret_cast<const int2*>(g->FAt.sent), g->x2_p, reinterpret_cast<float2*>(g->FAt.sax));
+        }
+        if ((rc = check_launch("fused_bind inputs"))) return rc;
+        g->bound_x1 = x1; g->bound_x2 = x2;
+    }
+    if (labels && labels != g->bound_labels) {
+        if (g->N > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->N, g->perm_v, labels, g->labels_p);
+        if ((rc = check_launch("fused_bind labels"))) return rc;
+        g->bound_labels = labels;
+    }
+    return MLLP_OK;
+}
+
+// ====================================================================================================
+// the whole model on the fused path
+// ====================================================================================================
+// one workgroup per CU, a multiple of the partition count (workgroup b works on partition b % NP)
+int fused_grid(const mllp_graph* g) { return std::max(std::min(g->n_cu, STAT_BLOCKS_MAX) / NP, 1) * NP; }
+
+static FwdJob16 fwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
                           float* h) {
     FwdJob16 J = {};
-    J.s = items_dev(o);
+    J.s = items_dev(o, false);
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.Z = w.Z; J.aux = w.aux;
     J.head = 0;
     return J;
 }
-static FwdJob1 fwd_job1(const Orient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
-                        float* h) {
+static FwdJob1 fwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, float* h) {
     FwdJob1 J = {};
-    J.s = items_dev(o);
-    J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
+    J.s = items_dev(o, true);
+    J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
     J.h = h; J.Z = w.Z; J.aux = w.aux;
     return J;
 }
 
-int fused_forward(const mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s) {
+int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s) {
     const int G = fused_grid(g);
     int rc;
+    if ((rc = fused_bind(g, m.x1, m.x2, head_mode == 2 ? m.labels : nullptr, s))) return rc;
     {   // folded weights of all five convs
         const float* cps[MODEL_CONVS] = {m.cp[0], m.cp[1], m.cp[2], m.cp[3], m.cp[4]};
         const int cins[MODEL_CONVS] = {1, 1, 16, 16, 16};
@@ -1175,26 +1368,27 @@ int fused_forward(const mllp_graph* g, const FusedModel& m, int head_mode, hipSt
     {   // linear_program_methods.py:241-242  layer 1, both directions
         FwdLaunch1 L = {};
         L.n_jobs = 2;
-        L.job[0] = fwd_job1(g->At, m.cp[0], m.c[0], m.x2, m.x1, m.h1v);     // w2s: dst = variables
-        L.job[1] = fwd_job1(g->A, m.cp[1], m.c[1], m.x1, m.x2, m.h1c);      // s2w: dst = constraints
+        L.job[0] = fwd_job1(g->FAt, m.cp[0], m.c[0], g->x1_p, m.h1v);     // w2s: dst = variables
+        L.job[1] = fwd_job1(g->FA, m.cp[1], m.c[1], g->x2_p, m.h1c);      // s2w: dst = constraints
         hipLaunchKernelGGL(fused_fwd1_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_fwd1"))) return rc;
     }
     {   // :244-245  layer 2 (simultaneous update)
         FwdLaunch16 L = {};
         L.n_jobs = 2;
-        L.job[0] = fwd_job16(g->At, m.cp[2], m.c[2], m.h1c, m.h1v, m.h2v);
-        L.job[1] = fwd_job16(g->A, m.cp[3], m.c[3], m.h1v, m.h1c, m.h2c);
+        L.job[0] = fwd_job16(g->FAt, m.cp[2], m.c[2], m.h1c, m.h1v, m.h2v);
+        L.job[1] = fwd_job16(g->FA, m.cp[3], m.c[3], m.h1v, m.h1c, m.h2c);
         hipLaunchKernelGGL(fused_fwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_fwd16 layer 2"))) return rc;
     }
     {   // :247 layer 3 (variables only) + :250 fc (+ loss)
         FwdLaunch16 L = {};
         L.n_jobs = 1;
-        L.job[0] = fwd_job16(g->At, m.cp[4], m.c[4], m.h2c, m.h2v, m.h3v);
+        L.job[0] = fwd_job16(g->FAt, m.cp[4], m.c[4], m.h2c, m.h2v, m.h3v);
         FwdJob16& J = L.job[0];
         J.head = head_mode;
-        J.fcw = m.fcw; J.fcb = m.fcb; J.inv_n = g->inv_n; J.labels = m.labels; J.inv_batch = m.inv_batch;
+        J.fcw = m.fcw; J.fcb = m.fcb; J.inv_n = g->inv_n_p; J.labels = g->labels_p; J.perm = g->perm_v;
+        J.inv_batch = m.inv_batch;
         J.logits = m.logits; J.g_out = m.d3v; J.head_part = m.head_part;
         hipLaunchKernelGGL(fused_fwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_fwd16 layer 3"))) return rc;
@@ -1202,10 +1396,17 @@ int fused_forward(const mllp_graph* g, const FusedModel& m, int head_mode, hipSt
     return MLLP_OK;
 }
 
-static BwdJob16 bwd_job16(const Orient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
+int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* dlogits, hipStream_t s) {
+    const int G = fused_grid(g);
+    hipLaunchKernelGGL(fused_head_bwd_kernel, dim3(G), dim3(FT), 0, s, (int)g->N, m.h3v, m.fcw, dlogits, g->perm_v, m.d3v,
+                       m.head_part);
+    return check_launch("fused_head_bwd");
+}
+
+static BwdJob16 bwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
                           const float* h, const float* dh_a, const float* dh_b, float* dx_dst, bool need_rec) {
     BwdJob16 J = {};
-    J.s = items_dev(o);
+    J.s = items_dev(o, false);
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux;
     J.rec = need_rec ? w.rec : nullptr;
@@ -1213,33 +1414,33 @@ static BwdJob16 bwd_job16(const Orient& o, const float* cp, const ConvWs& w, con
     J.stats = w.stats;
     return J;
 }
-static SrcJob16 src_job16(const Orient& o_src_major, const ConvWs& w, const float* x_rows, float* dx) {
+static SrcJob16 src_job16(const FusedOrient& o_src_major, const ConvWs& w, const float* x_rows, float* dx) {
     SrcJob16 J = {};
-    J.s = items_dev(o_src_major);
+    J.s = items_dev(o_src_major, false);
     J.x = x_rows; J.rec = w.rec; J.dx = dx;
     return J;
 }
-static BwdJob1 bwd_job1(const Orient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
-                        const float* h, const float* dh_a, const float* dh_b) {
+static BwdJob1 bwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, const float* h,
+                        const float* dh_a, const float* dh_b) {
     BwdJob1 J = {};
-    J.s = items_dev(o);
-    J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
+    J.s = items_dev(o, true);
+    J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
     J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux; J.stats = w.stats;
     return J;
 }
 
-// Backward chain (linear_program_methods.py:241-247 read backwards), one stream, independent sweeps share a launch:
+// Backward chain (linear_program_methods.py:241-247 read backwards), one stream:
 //   K1  C3  dst  (dh = d3v [premasked when it came from the fused head]) -> rec3, d2v
-//   K2  C3  src  -> d2c                      K2' C2V dst (dh = d2v) -> rec2v, d1v_a
-//   K3  C2C dst  (dh = d2c) -> rec2c, d1c_a  K3' C2V src -> d1c_b
-//   K4  C2C src  -> d1v_b                    K4' C1C dst (dh = d1c_a + d1c_b)
-//   K5  C1V dst  (dh = d1v_a + d1v_b)
+//   K2  C3  src  -> d2c                      K2' C2V dst (dh = d2v) -> rec2v, d1v
+//   K3  C2C dst  (dh = d2c) -> rec2c, d1c    K3' C2V src -> d1c_b
+//   K4  C2C src  -> d1v_b
+//   K5  C1C dst (dh = d1c + d1c_b) and C1V dst (dh = d1v + d1v_b) in one launch
 //   K6  reduce the statistics partials (+ fc partials), K7 finalize (node_kernels.hip)
 int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s) {
     const int G = fused_grid(g);
     int rc;
-    const Orient& A = g->A;      // rows = constraints
-    const Orient& At = g->At;    // rows = variables
+    const FusedOrient& A = g->FA;      // rows = constraints
+    const FusedOrient& At = g->FAt;    // rows = variables
     {   // K1
         BwdLaunch16 L = {};
         L.n_jobs = 1;
@@ -1247,7 +1448,7 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C3"))) return rc;
     }
-    {   // K2: C3 source-major (rows = constraints = A) and C2V destination-major
+    {   // K2: C3 source-major (rows = constraints) and C2V destination-major
         SrcLaunch16 S = {};
         S.n_jobs = 1;
         S.job[0] = src_job16(A, m.c[4], m.h2c, m.d2c);
@@ -1259,30 +1460,24 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C2V"))) return rc;
     }
-    {   // K3: C2C destination-major (rows = constraints) and C2V source-major (rows = constraints = A)
+    {   // K3: C2C destination-major (rows = constraints) and C2V source-major (rows = constraints)
         BwdLaunch16 L = {};
         L.n_jobs = 1;
         L.job[0] = bwd_job16(A, m.cp[3], m.c[3], m.h1v, m.h1c, m.h2c, m.d2c, nullptr, m.d1c, true);
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C2C"))) return rc;
         SrcLaunch16 S = {};
-        S.n_jobs = 1;
+        S.n_jobs = 2;
         S.job[0] = src_job16(A, m.c[2], m.h1c, m.d1c_b);
+        S.job[1] = src_job16(At, m.c[3], m.h1v, m.d1v_b);      // K4: C2C source-major (rows = variables)
         hipLaunchKernelGGL(fused_src16_kernel, dim3(G), dim3(FT), 0, s, S);
-        if ((rc = check_launch("fused_src16 C2V"))) return rc;
+        if ((rc = check_launch("fused_src16 C2V + C2C"))) return rc;
     }
-    {   // K4: C2C source-major (rows = variables = At) and C1C destination-major
-        SrcLaunch16 S = {};
-        S.n_jobs = 1;
-        S.job[0] = src_job16(At, m.c[3], m.h1v, m.d1v_b);
-        hipLaunchKernelGGL(fused_src16_kernel, dim3(G), dim3(FT), 0, s, S);
-        if ((rc = check_launch("fused_src16 C2C"))) return rc;
-    }
-    {   // K4' + K5: layer 1, both convs (inputs are data: no input gradients)
+    {   // K5: layer 1, both convs (inputs are data: no input gradients)
         BwdLaunch1 L = {};
         L.n_jobs = 2;
-        L.job[0] = bwd_job1(A, m.cp[1], m.c[1], m.x1, m.x2, m.h1c, m.d1c, m.d1c_b);
-        L.job[1] = bwd_job1(At, m.cp[0], m.c[0], m.x2, m.x1, m.h1v, m.d1v, m.d1v_b);
+        L.job[0] = bwd_job1(A, m.cp[1], m.c[1], g->x2_p, m.h1c, m.d1c, m.d1c_b);
+        L.job[1] = bwd_job1(At, m.cp[0], m.c[0], g->x1_p, m.h1v, m.d1v, m.d1v_b);
         hipLaunchKernelGGL(fused_bwd1_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd1"))) return rc;
     }
@@ -1290,7 +1485,7 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         ReduceArgs R = {};
         for (int i = 0; i < MODEL_CONVS; ++i) { R.stats[i] = m.c[i].stats; R.out[i] = m.c[i].red; }
         R.nblk = G;
-        R.head_part = premasked ? m.head_part : nullptr;
+        R.head_part = m.have_head_part ? m.head_part : nullptr;
         R.head_out = grads + 4704;
         R.loss_out = loss;
         hipLaunchKernelGGL(fused_reduce_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(FT), 0, s, R, MODEL_CONVS);

@@ -58,10 +58,6 @@ static int build_tiers(mllp_graph* g, Orient& o, const int* h_ptr) {
     if ((rc = upload(g, t.rows_wave.data(), t.rows_wave.size(), &o.rows_wave))) return rc;
     if ((rc = upload(g, t.chunks.data(), t.chunks.size(), &o.chunks))) return rc;
     if ((rc = upload(g, t.split.data(), t.split.size(), &o.split))) return rc;
-    HostItems it;
-    host_build_items(h_ptr, o.n_dst, ITEM_QUAD_MAX_DEG, ITEM_WAVE_MAX_DEG, &it);
-    o.n_iblock = it.n_block; o.n_iwave = it.n_wave; o.n_iquad = it.n_quad;
-    if ((rc = upload(g, it.rows.data(), it.rows.size(), &o.item_rows))) return rc;
     return MLLP_OK;
 }
 
@@ -143,6 +139,8 @@ extern "C" int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, con
         if ((rc = build_tiers(g, g->A, csr_ptr.data()))) break;
         if ((rc = build_tiers(g, g->At, csc_ptr.data()))) break;
         if ((rc = finish_common(g))) break;
+        g->h_csr_ptr = csr_ptr; g->h_csc_ptr = csc_ptr;
+        if (g->nnz < ((int64_t)32 << 20) && (rc = fused_graph_build(g, csr_ptr.data(), csc_ptr.data()))) break;
     } while (0);
     if (rc) {
         std::string keep = mllp_last_error();
@@ -206,6 +204,8 @@ extern "C" int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_
         if ((rc = build_tiers(g, g->A, h_rp.data()))) break;
         if ((rc = build_tiers(g, g->At, h_cp.data()))) break;
         if ((rc = finish_common(g))) break;
+        g->h_csr_ptr = h_rp; g->h_csc_ptr = h_cp;
+        if (g->nnz < ((int64_t)32 << 20) && (rc = fused_graph_build(g, h_rp.data(), h_cp.data()))) break;
     } while (0);
     if (rc) {
         std::string keep = mllp_last_error();

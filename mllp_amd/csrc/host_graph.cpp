@@ -134,26 +134,54 @@ void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTier
     t.short_rows = n_dst > 0 && (double)ptr[n_dst] / n_dst <= 16.0;
 }
 
-void host_build_items(const int* ptr, int n_dst, int quad_max_deg, int wave_max_deg, HostItems* out) {
-    HostItems& t = *out;
-    t = HostItems();
-    t.rows.resize((size_t)std::max(n_dst, 0));
-    if (n_dst <= 0) return;
-    // counting sort by degree, descending, stable in the row index.  Degrees above the wave tier's limit only
-    // need their relative order among few rows: sorted separately.
-    const int cap = wave_max_deg + 1;                       // bucket `cap` holds every longer row
-    std::vector<int> cnt((size_t)cap + 2, 0);
-    for (int r = 0; r < n_dst; ++r) cnt[std::min(ptr[r + 1] - ptr[r], cap)]++;
-    std::vector<int> start((size_t)cap + 2, 0);             // first position of each bucket, longest first
-    int pos = 0;
-    for (int d = cap; d >= 0; --d) { start[d] = pos; pos += cnt[d]; }
-    t.n_block = cnt[cap];
-    for (int d = cap - 1; d > quad_max_deg; --d) t.n_wave += cnt[d];
-    t.n_quad = n_dst - t.n_block - t.n_wave;
-    std::vector<int> fill(start);
-    for (int r = 0; r < n_dst; ++r) t.rows[fill[std::min(ptr[r + 1] - ptr[r], cap)]++] = r;
-    std::stable_sort(t.rows.begin(), t.rows.begin() + t.n_block,
-                     [&](int a, int b) { return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b]; });
+std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, int n_parts) {
+    const int n = (int)inst_nnz.size();
+    std::vector<int> order((size_t)n), part((size_t)n, 0);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return inst_nnz[a] > inst_nnz[b]; });
+    std::vector<int64_t> load((size_t)n_parts, 0);
+    for (int i : order) {
+        int best = 0;
+        for (int q = 1; q < n_parts; ++q)
+            if (load[q] < load[best]) best = q;
+        part[i] = best;
+        load[best] += std::max<int64_t>(inst_nnz[i], 1);      // empty instances are spread too
+    }
+    return part;
+}
+
+void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& inst_off, const std::vector<int>& inst_part,
+                             HostFusedOrient* out) {
+    HostFusedOrient& o = *out;
+    o = HostFusedOrient();
+    n = std::max(n, 0);
+    o.perm.resize((size_t)n);
+    o.inv.resize((size_t)n);
+    o.sptr.assign((size_t)n + 1, 0);
+    std::vector<int> node_part((size_t)n, 0);
+    for (size_t k = 0; k + 1 < inst_off.size(); ++k)
+        for (int64_t r = inst_off[k]; r < inst_off[k + 1] && r < n; ++r) node_part[(size_t)r] = inst_part[k];
+    for (int r = 0; r < n; ++r) o.perm[r] = r;
+    std::stable_sort(o.perm.begin(), o.perm.end(), [&](int a, int b) {
+        if (node_part[a] != node_part[b]) return node_part[a] < node_part[b];
+        return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b];
+    });
+    for (int q = 0; q <= FUSED_PARTS; ++q) o.row0[q] = 0;
+    for (int k = 0; k < n; ++k) {
+        const int r = o.perm[k], deg = ptr[r + 1] - ptr[r], q = node_part[r];
+        o.inv[r] = k;
+        o.sptr[k + 1] = o.sptr[k] + deg;
+        o.row0[q + 1]++;
+        for (int which = 0; which < 2; ++which) {
+            const int(&T)[3] = which ? FUSED_T1 : FUSED_T16;
+            FusedTiers& t = which ? o.t1[q] : o.t16[q];
+            if (deg > T[2]) t.n_block++;
+            else if (deg > T[1]) t.n_wave++;
+            else if (deg > T[0]) t.n_group++;
+            else t.n_base++;
+        }
+    }
+    for (int q = 0; q < FUSED_PARTS; ++q) o.row0[q + 1] += o.row0[q];
 }
 
 }  // namespace mllp

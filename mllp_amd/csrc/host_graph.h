@@ -40,18 +40,38 @@ struct HostTiers {
 };
 void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTiers* out);
 
-// Work list of the fused latency-regime kernels (fused_kernels.hip): the rows of one orientation ordered by their
-// number of nonzeros, descending (ties in row order), cut in three tiers:
-//   block tier  deg > wave_max_deg    one whole workgroup walks the row
-//   wave tier   deg > quad_max_deg    one wavefront walks the row
-//   quad tier   the rest (incl. empty rows): 16 rows per wavefront (16-channel sweeps: a quad of lanes per row) or
-//               64 rows per wavefront (1-channel sweeps: a lane per row); neighbours in the order have equal or
-//               nearly equal length, so the lanes of a wavefront finish together
-struct HostItems {
-    std::vector<int> rows;    // [n_dst]
-    int n_block = 0, n_wave = 0, n_quad = 0;
+// Node renumbering of the fused latency-regime kernels (fused_kernels.hip).  Constraints are renumbered by their
+// row length in A, variables by their column length (= row length in A^T), both descending with ties in the original
+// order.  In renumbered ids every sweep walks rows 0, 1, 2, ... whose lengths fall monotonically, so the rows a
+// wavefront shares have (nearly) equal length, every per-node tensor of the model is read and written with unit
+// stride, and the row tiers are contiguous id ranges:
+//   block  deg > T[2]   the whole workgroup walks the row
+//   wave   deg > T[1]   one wavefront
+//   group  deg > T[0]   a quarter of a wavefront (4 rows per wavefront)
+//   base   the rest (incl. empty rows): 16 rows per wavefront (a quad of lanes per row, 16-channel sweeps) or 64
+//          (a lane per row, 1-channel sweeps)
+// The block-diagonal structure is kept for locality: the instances are dealt to FUSED_PARTS partitions of (nearly)
+// equal nonzero count (longest-processing-time rule) and the renumbering is by (partition, length descending, original
+// id), the same partition for a constraint / variable and for every node it exchanges messages with.  Workgroup b of a
+// fused kernel works on partition b mod 8 -- the dispatcher deals workgroups round-robin over the 8 XCDs, so a
+// partition's gathers (an eighth of every node tensor) stay in one XCD's 4 MB L2.  Speed only: any placement is correct.
+constexpr int FUSED_PARTS = 8;
+struct FusedTiers {
+    int n_block = 0, n_wave = 0, n_group = 0, n_base = 0;
 };
-constexpr int ITEM_QUAD_MAX_DEG = 32, ITEM_WAVE_MAX_DEG = 512;
-void host_build_items(const int* ptr, int n_dst, int quad_max_deg, int wave_max_deg, HostItems* out);
+struct HostFusedOrient {
+    std::vector<int> perm;      // [n] renumbered id -> original id
+    std::vector<int> inv;       // [n] original id -> renumbered id
+    std::vector<int> sptr;      // [n + 1] entry offsets of the renumbered rows
+    int row0[FUSED_PARTS + 1];  // first renumbered id of every partition
+    FusedTiers t16[FUSED_PARTS], t1[FUSED_PARTS];   // tiers of the 16-channel / 1-channel sweeps inside each partition
+};
+constexpr int FUSED_T16[3] = {16, 64, 1024};     // quad / group (4 quads) / wave (16 quads) / block
+constexpr int FUSED_T1[3] = {16, 256, 4096};     // lane / group (16 lanes) / wave (64 lanes) / block
+// partition of every instance: LPT by nonzeros, ties and order deterministic
+std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, int n_parts);
+// inst_off: [n_inst + 1] offsets of the instances' nodes (rows of this orientation)
+void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& inst_off, const std::vector<int>& inst_part,
+                             HostFusedOrient* out);
 
 }  // namespace mllp

@@ -124,31 +124,47 @@ static void check_tiers(const int* ptr, int n_dst, const TierConfig& c) {
     CHECK(n_group == t.n_group);
 }
 
-static void check_items(const int* ptr, int n_dst, int qmax, int wmax) {
-    HostItems t;
-    host_build_items(ptr, n_dst, qmax, wmax, &t);
-    CHECK((int)t.rows.size() == n_dst && t.n_block + t.n_wave + t.n_quad == n_dst);
-    std::vector<int> seen(n_dst, 0);
-    int prev = 1 << 30, prev_row = -1;
-    for (int k = 0; k < n_dst; ++k) {
-        const int r = t.rows[k];
-        CHECK(r >= 0 && r < n_dst && !seen[r]);
-        seen[r] = 1;
-        const int deg = ptr[r + 1] - ptr[r];
-        CHECK(deg <= prev);                                   // descending
-        if (deg == prev) CHECK(r > prev_row);                 // ties in row order
-        if (k < t.n_block) CHECK(deg > wmax);
-        else if (k < t.n_block + t.n_wave) CHECK(deg > qmax && deg <= wmax);
-        else CHECK(deg <= qmax);
-        prev = deg; prev_row = r;
+static void check_fused(const int* ptr, int n, const std::vector<int64_t>& off, const std::vector<int>& part) {
+    HostFusedOrient o;
+    host_build_fused_orient(ptr, n, off, part, &o);
+    CHECK((int)o.perm.size() == n && (int)o.inv.size() == n && (int)o.sptr.size() == n + 1);
+    CHECK(o.row0[0] == 0 && o.row0[FUSED_PARTS] == n);
+    std::vector<int> node_part(n, -1);
+    for (size_t k = 0; k + 1 < off.size(); ++k)
+        for (int64_t r = off[k]; r < off[k + 1]; ++r) node_part[r] = part[k];
+    for (int q = 0; q < FUSED_PARTS; ++q) {
+        int prev = 1 << 30, prev_row = -1;
+        CHECK(o.row0[q] <= o.row0[q + 1]);
+        for (int k = o.row0[q]; k < o.row0[q + 1]; ++k) {
+            const int r = o.perm[k];
+            CHECK(r >= 0 && r < n && o.inv[r] == k && node_part[r] == q);
+            const int deg = ptr[r + 1] - ptr[r];
+            CHECK(deg <= prev);
+            if (deg == prev) CHECK(r > prev_row);
+            CHECK(o.sptr[k + 1] - o.sptr[k] == deg);
+            prev = deg; prev_row = r;
+        }
+        for (int which = 0; which < 2; ++which) {
+            const FusedTiers& t = which ? o.t1[q] : o.t16[q];
+            const int (&T)[3] = which ? FUSED_T1 : FUSED_T16;
+            CHECK(t.n_block + t.n_wave + t.n_group + t.n_base == o.row0[q + 1] - o.row0[q]);
+            for (int k = o.row0[q]; k < o.row0[q + 1]; ++k) {
+                const int deg = o.sptr[k + 1] - o.sptr[k], kk = k - o.row0[q];
+                if (kk < t.n_block) CHECK(deg > T[2]);
+                else if (kk < t.n_block + t.n_wave) CHECK(deg > T[1] && deg <= T[2]);
+                else if (kk < t.n_block + t.n_wave + t.n_group) CHECK(deg > T[0] && deg <= T[1]);
+                else CHECK(deg <= T[0]);
+            }
+        }
     }
+    CHECK(o.sptr[n] == ptr[n]);
 }
 
 int main() {
     std::mt19937 rng(12345);
     for (int round = 0; round < 6; ++round) {
         const int n_inst = round == 0 ? 1 : 5 + 9 * round;
-        Raw r = random_batch(rng, n_inst, 70);
+        Raw r = random_batch(rng, n_inst, round == 3 ? 90 : 70);
         HostBatch b;
         std::string err;
         const int rc = host_build_batch(n_inst, r.m.data(), r.n.data(), r.indptr.data(), r.idx.data(), r.val.data(),
@@ -162,12 +178,17 @@ int main() {
                 check_tiers(b.csr_ptr.data(), (int)b.M, c);
                 check_tiers(b.csc_ptr.data(), (int)b.N, c);
             }
-        for (int qm : {0, 2, 32})
-            for (int wm : {2, 40, 512}) {
-                if (wm < qm) continue;
-                check_items(b.csr_ptr.data(), (int)b.M, qm, wm);
-                check_items(b.csc_ptr.data(), (int)b.N, qm, wm);
-            }
+        {
+            std::vector<int64_t> nz(n_inst);
+            for (int k = 0; k < n_inst; ++k) nz[k] = b.csr_ptr[b.pm[k + 1]] - b.csr_ptr[b.pm[k]];
+            const std::vector<int> part = host_partition_instances(nz, FUSED_PARTS);
+            std::vector<int64_t> load(FUSED_PARTS, 0);
+            int64_t mx = 0;
+            for (int k = 0; k < n_inst; ++k) { CHECK(part[k] >= 0 && part[k] < FUSED_PARTS); load[part[k]] += nz[k]; mx = std::max(mx, nz[k]); }
+            for (int q = 0; q < FUSED_PARTS; ++q) CHECK(load[q] <= b.nnz / FUSED_PARTS + mx + n_inst);    // LPT bound
+            check_fused(b.csr_ptr.data(), (int)b.M, b.pm, part);
+            check_fused(b.csc_ptr.data(), (int)b.N, b.pn, part);
+        }
     }
     {   // empty batch and argument errors
         HostBatch b;

@@ -59,9 +59,19 @@ struct Orient {
     float* scratch = nullptr;   // [n_slots x SCRATCH_NS] partial states of this orientation's split rows
     int tier_wave = 0;          // rows with more nonzeros than this are skipped by the group tier
     bool short_rows = false;    // mean row length <= 16: group tier runs one nonzero slot per pass
-    // work list of the fused latency-regime kernels (host_graph.h::HostItems): rows by length, three tiers
-    int* item_rows = nullptr;   // [n_dst]
-    int n_iblock = 0, n_iwave = 0, n_iquad = 0;
+};
+// One orientation of the fused latency-regime path in RENUMBERED node ids (host_graph.h::HostFusedOrient)
+struct FusedTiersDev {
+    int n_block = 0, n_wave = 0, n_group = 0, n_base = 0;
+};
+constexpr int FUSED_NP = 8;     // partitions of the instances (host_graph.h::FUSED_PARTS): one per XCD
+struct FusedOrient {
+    int n_dst = 0, n_src = 0;
+    int* sptr = nullptr;        // [n_dst + 1]
+    int* sent = nullptr;        // [nnz][2] {source id (renumbered), value bits}
+    float* sax = nullptr;       // [nnz][2] {a_ij, x_src} of the bound layer-1 inputs (scalar node features are data)
+    int row0[FUSED_NP + 1] = {};
+    FusedTiersDev t16[FUSED_NP], t1[FUSED_NP];
 };
 constexpr int SCRATCH_NS = 20;  // floats per partial-state slot of a split row
 
@@ -75,10 +85,25 @@ struct mllp_graph {
     int* inst_ptr_n = nullptr;   // [n_inst + 1] device
     int* inst_ptr_m = nullptr;   // [n_inst + 1] device
     std::vector<int64_t> h_inst_ptr_n, h_inst_ptr_m;
+    std::vector<int> h_csr_ptr, h_csc_ptr;     // host copies of the row pointers (the fused path is built from them)
     int tier_wave = 0, tier_block = 0, chunk_nnz = 0;
     int max_inst_n = 0;
     int n_cu = 256;              // compute units of the device: grid size of the persistent fused kernels
     int path = 0;                // whole-model path: 0 = by size (fused below 32 M nonzeros), 1 = generic / tiled, 2 = fused
+    // fused path: renumbered copies of both orientations, permutations, renumbered copies of the bound inputs
+    bool fused_built = false;
+    mllp::FusedOrient FA, FAt;   // FA: rows = constraints, FAt: rows = variables
+    int* perm_v = nullptr;       // [N] renumbered variable id -> original
+    int* perm_c = nullptr;       // [M]
+    int* inv_v = nullptr;        // [N] original -> renumbered
+    int* inv_c = nullptr;        // [M]
+    float* inv_n_p = nullptr;    // [N] 1 / n_k in renumbered order
+    float* x1_p = nullptr;       // [N] bound inputs in renumbered order
+    float* x2_p = nullptr;       // [M]
+    float* labels_p = nullptr;   // [N]
+    const void* bound_x1 = nullptr;
+    const void* bound_x2 = nullptr;
+    const void* bound_labels = nullptr;
     // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
     // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
     hipStream_t aux = nullptr;
@@ -191,10 +216,14 @@ struct FusedModel {
     float *h1v, *h1c, *h2v, *h2c, *h3v;
     float *d3v, *d2v, *d2c, *d1v, *d1c, *d1v_b, *d1c_b;
     float *logits, *head_part;
+    bool have_head_part;         // fused_backward sums the fc partials (from fused_forward mode 2 or fused_head_backward)
 };
+int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr);   // allocates: creation / set_path only
 int fused_grid(const mllp_graph* g);
 // head_mode 1: logits (h3v kept), 2: logits + BCE + masked dL/dh3v in d3v + fc partials
-int fused_forward(const mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s);
+int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s);
+// d3v = dlogits (original variable order) x fc weight in renumbered order, fc gradient partials
+int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* dlogits, hipStream_t s);
 // premasked: d3v and the fc partials come from fused_forward(head_mode 2); else d3v = dL/dh3v (unmasked) and the
 // caller has produced the fc gradient itself
 int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s);

@@ -37,8 +37,24 @@ namespace mllp {
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-constexpr int FT = 1024;            // threads per workgroup
+// Timing build only (`make timing`, libmllp_hip_timing.so): MLLP_FUSED_ABL masks parts of fused_bwd16_kernel out
+// (results WRONG): 1 = no sweep, 2 = no statistics, 4 = no input-gradient GEMMs, 8 = no record store, 16 = no
+// prologue GEMMs.  The product build compiles FUSED_ABL(bit) to false.
+#ifdef MLLP_TIMING_BUILD
+static int g_fused_abl = [] {
+    const char* e = getenv("MLLP_FUSED_ABL");
+    return e ? atoi(e) : 0;
+}();
+#define FUSED_ABL(bit) ((J.abl & (bit)) != 0)
+#else
+#define FUSED_ABL(bit) false
+#endif
+
+constexpr int FT = 768;             // threads per workgroup of the sweep kernels: 3 wavefronts per SIMD leave 168 VGPRs
+                                    // each -- at 1024 threads (128 VGPRs) the statistics accumulators were spilled to
+                                    // scratch and re-loaded per item (42 of the 75 us of fused_bwd16_kernel)
 constexpr int FW = FT / 64;         // wavefronts per workgroup
+constexpr int RT = 1024;            // threads of the small reduction / head kernels
 constexpr int MAXJOBS = 2;
 
 constexpr int NP = FUSED_NP;        // partitions (one per XCD: workgroup b works on partition b % NP)
@@ -210,6 +226,22 @@ __device__ __forceinline__ RowSlot block_slot(const ItemsDev& s, int k, int tid)
 __device__ __forceinline__ int slot_count(const RowSlot& r) {
     return r.first < r.end ? (r.end - r.first + r.stride - 1) / r.stride : 0;
 }
+__device__ __forceinline__ RowSlot empty_slot() {
+    RowSlot r;
+    r.row = -1; r.first = 0; r.stride = 1; r.end = 0; r.mode = 0; r.writer = false;
+    return r;
+}
+// Software pipeline over the items of a wavefront.  Its memory round trips are what a sweep waits for (PMC of the
+// first version: 69 % of the wave cycles in s_waitcnt at 4 wavefronts per SIMD), so an item's dependent chain
+// "row pointers -> entries -> gathers" and its row data are fetched one item ahead: the slot of item i + 1 is
+// computed (row pointers requested) when item i starts, its first entries and its row data are requested when the
+// sweep of item i ends -- they land during item i's epilogue -- and item i + 1 starts by issuing its gathers.
+// `lanes_per_entry`: the quad lanes that fetch distinct entries (4: slots part, 2: slots part & 1)
+template <int LPE>
+__device__ __forceinline__ int2 first_entries(const ItemsDev& s, const RowSlot& r, int part) {
+    const int k = LPE == 4 ? part : (part & 1);
+    return k < slot_count(r) ? s.sent[r.first + k * r.stride] : make_int2(0, 0);
+}
 // sums / maxima over the units that share a row (quad layout: values replicated inside a quad or owned per part)
 __device__ __forceinline__ float shared_sum4(float v, int mode) {
     return mode == 1 ? quads_sum<16>(v) : quads_sum<64>(v);
@@ -257,47 +289,51 @@ struct SoftState {
     float m, L, u;
 };
 
-// the attention sweep of one quad over its nonzeros (first, first + stride, ... < end): online segment softmax.
-// The four lanes of the quad fetch four consecutive entries of the row and share them by DPP; the entries of the
-// next four are in flight while the current four source rows are gathered.
-__device__ __forceinline__ void fwd16_edges(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r,
-                                            const float4& qp, float t, int part, SoftState& st) {
-    const int n_mine = slot_count(r);
-    int2 en = part < n_mine ? s.sent[r.first + part * r.stride] : make_int2(0, 0);
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        const int colm = en.x;
-        const float am = __int_as_float(en.y);
-        const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
-        const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am), a2 = quad_bcast<2>(am), a3 = quad_bcast<3>(am);
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
-        float4 x0 = f4zero(), x1 = f4zero(), x2 = f4zero(), x3 = f4zero();
-        if (ok0) x0 = ld4(X + (size_t)c0 * 16 + 4 * part);
-        if (ok1) x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
-        if (ok2) x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
-        if (ok3) x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
-        const int kn = k0 + 4 + part;
-        en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
-        const float d0 = ok0 ? fmaf(a0, t, quad_sum(dot4(qp, x0))) : NEG_BIG;
-        const float d1 = ok1 ? fmaf(a1, t, quad_sum(dot4(qp, x1))) : NEG_BIG;
-        const float d2 = ok2 ? fmaf(a2, t, quad_sum(dot4(qp, x2))) : NEG_BIG;
-        const float d3 = ok3 ? fmaf(a3, t, quad_sum(dot4(qp, x3))) : NEG_BIG;
-        const float mi = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
-        if (__any(mi > st.m)) {          // some row of this wavefront moves its running max: rescale those rows
-            const float mn = fmaxf(st.m, mi);
-            const float sc = exp_acc(st.m - mn);
-            st.L *= sc; st.u *= sc;
-            st.Z = f4scale(st.Z, sc);
-            st.m = mn;
-        }
-        const float p0 = ok0 ? exp_acc(d0 - st.m) : 0.0f, p1 = ok1 ? exp_acc(d1 - st.m) : 0.0f;
-        const float p2 = ok2 ? exp_acc(d2 - st.m) : 0.0f, p3 = ok3 ? exp_acc(d3 - st.m) : 0.0f;
-        st.L += (p0 + p1) + (p2 + p3);
-        st.u = fmaf(p0, a0, fmaf(p1, a1, fmaf(p2, a2, fmaf(p3, a3, st.u))));
-        fma4(p0, x0, st.Z);
-        fma4(p1, x1, st.Z);
-        fma4(p2, x2, st.Z);
-        fma4(p3, x3, st.Z);
+// four gathered source rows of a quad and their matrix entries
+struct Gather4 {
+    float4 x0, x1, x2, x3;
+    float a0, a1, a2, a3;
+};
+// issue the gathers of slots k0 .. k0 + 3 from the entries `en` (one per lane of the quad), then fetch the next
+// four entries into `en`
+__device__ __forceinline__ void gather4_issue(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r, int n_mine,
+                                              int k0, int part, int2& en, Gather4& g) {
+    const int colm = en.x;
+    const float am = __int_as_float(en.y);
+    const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
+    g.a0 = quad_bcast<0>(am); g.a1 = quad_bcast<1>(am); g.a2 = quad_bcast<2>(am); g.a3 = quad_bcast<3>(am);
+    g.x0 = f4zero(); g.x1 = f4zero(); g.x2 = f4zero(); g.x3 = f4zero();
+    if (k0 < n_mine) g.x0 = ld4(X + (size_t)c0 * 16 + 4 * part);
+    if (k0 + 1 < n_mine) g.x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
+    if (k0 + 2 < n_mine) g.x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
+    if (k0 + 3 < n_mine) g.x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
+    const int kn = k0 + 4 + part;
+    en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
+}
+
+// online segment softmax over four gathered nonzeros
+__device__ __forceinline__ void fwd16_step(const Gather4& g, int k0, int n_mine, const float4& qp, float t, SoftState& st) {
+    const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
+    const float d0 = ok0 ? fmaf(g.a0, t, quad_sum(dot4(qp, g.x0))) : NEG_BIG;
+    const float d1 = ok1 ? fmaf(g.a1, t, quad_sum(dot4(qp, g.x1))) : NEG_BIG;
+    const float d2 = ok2 ? fmaf(g.a2, t, quad_sum(dot4(qp, g.x2))) : NEG_BIG;
+    const float d3 = ok3 ? fmaf(g.a3, t, quad_sum(dot4(qp, g.x3))) : NEG_BIG;
+    const float mi = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
+    if (__any(mi > st.m)) {          // some row of this wavefront moves its running max: rescale those rows
+        const float mn = fmaxf(st.m, mi);
+        const float sc = exp_acc(st.m - mn);
+        st.L *= sc; st.u *= sc;
+        st.Z = f4scale(st.Z, sc);
+        st.m = mn;
     }
+    const float p0 = ok0 ? exp_acc(d0 - st.m) : 0.0f, p1 = ok1 ? exp_acc(d1 - st.m) : 0.0f;
+    const float p2 = ok2 ? exp_acc(d2 - st.m) : 0.0f, p3 = ok3 ? exp_acc(d3 - st.m) : 0.0f;
+    st.L += (p0 + p1) + (p2 + p3);
+    st.u = fmaf(p0, g.a0, fmaf(p1, g.a1, fmaf(p2, g.a2, fmaf(p3, g.a3, st.u))));
+    fma4(p0, g.x0, st.Z);
+    fma4(p1, g.x1, st.Z);
+    fma4(p2, g.x2, st.Z);
+    fma4(p3, g.x3, st.Z);
 }
 
 // the units that share a row hold partial states: every lane ends with the row's state
@@ -318,14 +354,17 @@ struct HeadAcc {
     float b, l;    // db_fc, loss (part-0 lanes)
 };
 
-// per-row prologue + sweep + epilogue of one job
-__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const RowSlot& r, int part,
+// per-row prologue + sweep + epilogue of one job.  (xd, en): this item's destination row and first entries, fetched
+// while the previous item ran; (rn, xdn, enn): the same for the next item, requested here
+__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const RowSlot& r, const float4& xd, int2 en,
+                                          const RowSlot& rn, float4& xdn, int2& enn, int part,
                                           int lane, float* merge_lds, float* tiles, HeadAcc& ha) {
-    const bool have = r.row >= 0;
+    const int n_mine = slot_count(r);
+    Gather4 gt;
+    gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
     float4 qp;
     float t;
     {   // q' = Pq x + pq0 on the MFMA (rows of the wavefront through tile 0, kept for the epilogue; result through tile 1)
-        const float4 xd = have ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
         float ax_[4];
         tile_put(tiles, xd, lane);
         tile_rows(tiles, lane, ax_);
@@ -335,7 +374,16 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     }
     SoftState st;
     st.Z = f4zero(); st.m = NEG_BIG; st.L = 0.0f; st.u = 0.0f;
-    fwd16_edges(J.s, J.x_src, r, qp, t, part, st);
+    for (int k0 = 0;;) {
+        fwd16_step(gt, k0, n_mine, qp, t, st);
+        k0 += 4;
+        if (!__any(k0 < n_mine)) break;
+        gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
+    }
+    // the next item's row and first entries travel while this one finishes
+    xdn = rn.row >= 0 ? ld4(J.x_dst + (size_t)rn.row * 16 + 4 * part) : f4zero();
+    enn = first_entries<4>(J.s, rn, part);
+
     if (r.mode >= 1) soft_merge(st, r.mode);
     if (r.mode == 3) {       // merge the 16 wavefronts of the workgroup through LDS (fixed order)
         const int wave = threadIdx.x >> 6;
@@ -406,6 +454,7 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
 }
 
 // {dW_fc[16], db, loss} of the workgroup -> head_part[blockIdx][18] (wave order)
+template <int NW>
 __device__ __forceinline__ void head_partials_store(HeadAcc& ha, float* head_lds, float* head_part, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     ha.w.x = quads_sum<64>(ha.w.x); ha.w.y = quads_sum<64>(ha.w.y);
@@ -420,7 +469,7 @@ __device__ __forceinline__ void head_partials_store(HeadAcc& ha, float* head_lds
     __syncthreads();
     if (tid < 18) {
         float v = 0.0f;
-        for (int w = 0; w < FW; ++w) v += head_lds[w * 18 + tid];
+        for (int w = 0; w < NW; ++w) v += head_lds[w * 18 + tid];
         head_part[(size_t)blockIdx.x * 18 + tid] = v;
     }
 }
@@ -464,16 +513,29 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
         const PartTiers P = J.s.part[px];
         if (J.head == 2) head_part = J.head_part;
         // block tier: the whole workgroup walks one long row at a time (longest rows first)
-        for (int k = bi; k < P.n_block; k += gp)
-            fwd16_row(J, Ws_[j], block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds, tiles, ha);
+        const RowSlot none = empty_slot();
+        float4 xd, xdn;
+        int2 en, enn;
+        for (int k = bi; k < P.n_block; k += gp) {
+            const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
+            xd = ld4(J.x_dst + (size_t)r.row * 16 + 4 * part);
+            en = first_entries<4>(J.s, r, part);
+            fwd16_row(J, Ws_[j], r, xd, en, none, xdn, enn, part, lane, merge_lds, tiles, ha);
+        }
         // wave loop: the items of all jobs form one sequence dealt round-robin over the partition's wavefronts
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw)
-            fwd16_row(J, Ws_[j], item_slot<4>(J.s, P, it, lane), part, lane, merge_lds, tiles, ha);
+        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
+        en = first_entries<4>(J.s, r, part);
+        for (; it < n_items; it += nw) {
+            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
+            fwd16_row(J, Ws_[j], r, xd, en, rn, xdn, enn, part, lane, merge_lds, tiles, ha);
+            r = rn; xd = xdn; en = enn;
+        }
         base += n_items;
     }
-    if (head_part) head_partials_store(ha, head_lds, head_part, tid);     // (uniform: one job at most has a head)
+    if (head_part) head_partials_store<FW>(ha, head_lds, head_part, tid);     // (uniform: one job at most has a head)
 }
 
 // ====================================================================================================
@@ -637,6 +699,9 @@ struct BwdJob16 {
     float* __restrict__ rec;           // [n_dst, REC_W] or nullptr (no source-major sweep follows)
     float* __restrict__ dx_dst;        // [n_dst, 16] or nullptr
     float* __restrict__ stats;         // [grid, STAT_FLOATS]
+#ifdef MLLP_TIMING_BUILD
+    int abl;
+#endif
 };
 struct BwdLaunch16 {
     BwdJob16 job[MAXJOBS];
@@ -652,61 +717,57 @@ struct BwdState {
     float ds, dt;
 };
 
-__device__ __forceinline__ void bwd16_edges(const ItemsDev& s, const float* __restrict__ X, const RowSlot& r,
-                                            const float4& qp, const float4& gv, float t, float m, float rinv, float ge,
-                                            float cc, int part, BwdState& st) {
-    const int n_mine = slot_count(r);
-    int2 en = part < n_mine ? s.sent[r.first + part * r.stride] : make_int2(0, 0);
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        const int colm = en.x;
-        const float am = __int_as_float(en.y);
-        const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
-        const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am), a2 = quad_bcast<2>(am), a3 = quad_bcast<3>(am);
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
-        float4 x0 = f4zero(), x1 = f4zero(), x2 = f4zero(), x3 = f4zero();
-        if (ok0) x0 = ld4(X + (size_t)c0 * 16 + 4 * part);
-        if (ok1) x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
-        if (ok2) x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
-        if (ok3) x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
-        const int kn = k0 + 4 + part;
-        en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
-#define MLLP_BWD_SLOT(OK, A_, X_)                                                          \
+__device__ __forceinline__ void bwd16_step(const Gather4& g, int k0, int n_mine, const float4& qp, const float4& gv, float t,
+                                           float m, float rinv, float ge, float cc, BwdState& st) {
+#define MLLP_BWD_SLOT(K, A_, X_)                                                           \
     {                                                                                      \
         const float l_ = fmaf(A_, t, quad_sum(dot4(qp, X_)));                              \
-        const float al_ = OK ? exp_acc(l_ - m) * rinv : 0.0f;                              \
+        const float al_ = (k0 + K < n_mine) ? exp_acc(l_ - m) * rinv : 0.0f;               \
         const float dl_ = al_ * (quad_sum(dot4(gv, X_)) + fmaf(A_, ge, cc));               \
         st.ds += dl_;                                                                      \
         st.dt = fmaf(dl_, A_, st.dt);                                                      \
         fma4(dl_, X_, st.dq);                                                              \
     }
-        MLLP_BWD_SLOT(ok0, a0, x0)
-        MLLP_BWD_SLOT(ok1, a1, x1)
-        MLLP_BWD_SLOT(ok2, a2, x2)
-        MLLP_BWD_SLOT(ok3, a3, x3)
+    MLLP_BWD_SLOT(0, g.a0, g.x0)
+    MLLP_BWD_SLOT(1, g.a1, g.x1)
+    MLLP_BWD_SLOT(2, g.a2, g.x2)
+    MLLP_BWD_SLOT(3, g.a3, g.x3)
 #undef MLLP_BWD_SLOT
-    }
+}
+
+// the row data of a destination-major backward item (fetched one item ahead)
+struct BwdRow {
+    float4 ga, gb, h, x, Z, ax;
+};
+__device__ __forceinline__ void bwd16_fetch(const BwdJob16& J, const RowSlot& r, int part, BwdRow& d) {
+    const bool have = r.row >= 0;
+    const size_t ro = have ? (size_t)r.row * 16 + 4 * part : 0;
+    const float4 z4 = f4zero();
+    d.ga = have ? ld4(J.dh_a + ro) : z4;
+    d.gb = (J.dh_b && have) ? ld4(J.dh_b + ro) : z4;
+    d.h = (J.h && have) ? ld4(J.h + ro) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    d.x = have ? ld4(J.x_dst + ro) : z4;
+    d.Z = have ? ld4(J.Z + ro) : z4;
+    d.ax = have ? reinterpret_cast<const float4*>(J.aux)[r.row] : z4;   // {u, rowmax, rinv, S}
 }
 
 // tiles of a wavefront in the destination-major backward sweep
 constexpr int TB_G = 0, TB_X = 1, TB_Z = 2, TB_DQ = 3, TB_SC = 4, TB_E = 5, TB_N = 6;
 
-__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, int part,
+__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, const BwdRow& rd, int2 en,
+                                          const RowSlot& rn, BwdRow& rdn, int2& enn, int part,
                                           int lane, float* merge_lds, float* tiles, f32x4m (&acc)[STAT_TILES]) {
     const bool have = r.row >= 0;
     const bool writer = r.writer;
+    const int n_mine = FUSED_ABL(1) ? 0 : slot_count(r);
+    Gather4 gt;
+    gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
     float4 qp, gv;
     float t, m, rinv, ge, cc;
     {   // everything of the row that the sweep does not need stays in the tiles G, X, Z, E until the statistics
-        const size_t ro = have ? (size_t)r.row * 16 + 4 * part : 0;
-        float4 g = have ? ld4(J.dh_a + ro) : f4zero();
-        if (J.dh_b && have) g = f4add(g, ld4(J.dh_b + ro));
-        if (J.h && have) {
-            const float4 hv = ld4(J.h + ro);
-            g = make_float4(hv.x > 0.0f ? g.x : 0.0f, hv.y > 0.0f ? g.y : 0.0f, hv.z > 0.0f ? g.z : 0.0f, hv.w > 0.0f ? g.w : 0.0f);
-        }
-        const float4 xd = have ? ld4(J.x_dst + ro) : f4zero();
-        const float4 Zn = have ? ld4(J.Z + ro) : f4zero();
-        const float4 ax = have ? reinterpret_cast<const float4*>(J.aux)[r.row] : f4zero();   // {u, rowmax, rinv, S}
+        float4 g = f4add(rd.ga, rd.gb);
+        g = make_float4(rd.h.x > 0.0f ? g.x : 0.0f, rd.h.y > 0.0f ? g.y : 0.0f, rd.h.z > 0.0f ? g.z : 0.0f, rd.h.w > 0.0f ? g.w : 0.0f);
+        const float4 xd = rd.x, Zn = rd.Z, ax = rd.ax;
         // gv = Wv^T g and q' = Pq x + pq0 on the MFMA; the results come back through the (still unused) tiles DQ and SC
         float ag_[4], ax_[4];
         tile_put(tiles + TB_G * TILE, g, lane);
@@ -715,8 +776,10 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         tile_put(tiles + TB_E * TILE, (have && part == 0) ? make_float4(1.0f, ax.w, ax.x, 0.0f) : f4zero(), lane);
         tile_rows(tiles + TB_G * TILE, lane, ag_);
         tile_rows(tiles + TB_X * TILE, lane, ax_);
-        tile_put_result(tiles + TB_DQ * TILE, mat_apply(ag_, matB_lds(W.BWvT, lane), splat4(0.0f)), lane);
-        tile_put_result(tiles + TB_SC * TILE, mat_apply(ax_, matB_lds(W.BPq, lane), splat4(W.pq0[lane & 15])), lane);
+        if (!FUSED_ABL(16)) {
+            tile_put_result(tiles + TB_DQ * TILE, mat_apply(ag_, matB_lds(W.BWvT, lane), splat4(0.0f)), lane);
+            tile_put_result(tiles + TB_SC * TILE, mat_apply(ax_, matB_lds(W.BPq, lane), splat4(W.pq0[lane & 15])), lane);
+        }
         gv = tile_get(tiles + TB_DQ * TILE, lane);
         qp = tile_get(tiles + TB_SC * TILE, lane);
         t = quad_sum(dot4(lds4(W.Pt + 4 * part), xd)) + W.pt0;
@@ -725,7 +788,7 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         const float Dn = quad_sum(dot4(gv, Zn)) + gb * ax.w + ge * ax.x;
         cc = gb - Dn;
         m = ax.y; rinv = ax.z;
-        if (writer && J.rec) {
+        if (writer && J.rec && !FUSED_ABL(8)) {
             float* rr = J.rec + (size_t)r.row * REC_W;
             *reinterpret_cast<float4*>(rr + 4 * part) = qp;
             *reinterpret_cast<float4*>(rr + 16 + 4 * part) = gv;
@@ -735,7 +798,15 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
     }
     BwdState st;
     st.dq = f4zero(); st.ds = 0.0f; st.dt = 0.0f;
-    bwd16_edges(J.s, J.x_src, r, qp, gv, t, m, rinv, ge, cc, part, st);
+    for (int k0 = 0;;) {
+        bwd16_step(gt, k0, n_mine, qp, gv, t, m, rinv, ge, cc, st);
+        k0 += 4;
+        if (!__any(k0 < n_mine)) break;
+        gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
+    }
+    // the next item's row data and first entries travel while this one finishes
+    bwd16_fetch(J, rn, part, rdn);
+    enn = first_entries<4>(J.s, rn, part);
     if (r.mode >= 1) {
         st.ds = shared_sum4(st.ds, r.mode);
         st.dt = shared_sum4(st.dt, r.mode);
@@ -762,7 +833,7 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         if (threadIdx.x >= 64) return;      // wave-uniform: the row's outputs and statistics belong to wavefront 0
     }
     tile_put(tiles + TB_DQ * TILE, st.dq, lane);
-    if (J.dx_dst) {          // dx_i = Ws^T g_i + Pq^T dq'_i + ds_i Pb + dt_i Pt
+    if (J.dx_dst && !FUSED_ABL(4)) {          // dx_i = Ws^T g_i + Pq^T dq'_i + ds_i Pb + dt_i Pt
         float ag_[4], adq_[4];
         tile_rows(tiles + TB_G * TILE, lane, ag_);
         tile_rows(tiles + TB_DQ * TILE, lane, adq_);
@@ -775,6 +846,7 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
     }
     // statistics (node_kernels.hip::param_stats16_kernel): operands with m / n = channel, k = row.  A row shared by
     // several quads is counted once: only its writer keeps it, the other rows of the tiles become zeros
+    if (FUSED_ABL(2)) return;
     if (r.mode >= 1 && !writer) {
         const float4 z4 = f4zero();
         tile_put(tiles + TB_G * TILE, z4, lane);
@@ -785,12 +857,20 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
     }
     tile_put(tiles + TB_SC * TILE, (writer && part == 0) ? make_float4(st.ds, st.dt, 0.0f, 0.0f) : f4zero(), lane);
     float cg[4], cdq[4], csc[4], cx[4], cz[4], ce[4];
+    if (FUSED_ABL(64)) {
+        for (int s = 0; s < 4; ++s) { cg[s] = cdq[s] = csc[s] = cx[s] = cz[s] = ce[s] = (float)lane; }
+    } else {
     tile_cols(tiles + TB_G * TILE, lane, cg);
     tile_cols(tiles + TB_DQ * TILE, lane, cdq);
     tile_cols(tiles + TB_SC * TILE, lane, csc);
     tile_cols(tiles + TB_X * TILE, lane, cx);
     tile_cols(tiles + TB_Z * TILE, lane, cz);
     tile_cols(tiles + TB_E * TILE, lane, ce);
+    }
+    if (FUSED_ABL(32)) {
+        asm volatile("" :: "v"(cg[0]), "v"(cdq[1]), "v"(csc[2]), "v"(cx[3]), "v"(cz[0]), "v"(ce[1]));
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[s], cx[s], acc[0], 0, 0, 0);    // T0 g x^T
@@ -835,12 +915,25 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
         f32x4m acc[STAT_TILES];
 #pragma unroll
         for (int i = 0; i < STAT_TILES; ++i) acc[i] = splat4(0.0f);
-        for (int k = bi; k < P.n_block; k += gp)
-            bwd16_row(J, Ws_[j], block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds, tiles, acc);
+        const RowSlot none = empty_slot();
+        BwdRow rd, rdn;
+        int2 en, enn;
+        for (int k = bi; k < P.n_block; k += gp) {
+            const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
+            bwd16_fetch(J, r, part, rd);
+            en = first_entries<4>(J.s, r, part);
+            bwd16_row(J, Ws_[j], r, rd, en, none, rdn, enn, part, lane, merge_lds, tiles, acc);
+        }
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw)
-            bwd16_row(J, Ws_[j], item_slot<4>(J.s, P, it, lane), part, lane, merge_lds, tiles, acc);
+        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        bwd16_fetch(J, r, part, rd);
+        en = first_entries<4>(J.s, r, part);
+        for (; it < n_items; it += nw) {
+            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
+            bwd16_row(J, Ws_[j], r, rd, en, rn, rdn, enn, part, lane, merge_lds, tiles, acc);
+            r = rn; rd = rdn; en = enn;
+        }
         base += n_items;
         // the workgroup's partial statistics: the 16 wavefronts' tiles summed in wave order, one tile at a time
         __syncthreads();
@@ -875,12 +968,35 @@ struct SrcLaunch16 {
     int n_jobs;
 };
 
-__device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, int part, int lane, float* merge_lds) {
-    const bool have = r.row >= 0;
-    const float4 xj = have ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
-    float4 acc = f4zero();
+// two gathered destination records of a quad
+struct GatherRec2 {
+    float4 q0, g0, s0, q1, g1, s1;
+    float a0, a1, cc0, cc1;
+};
+__device__ __forceinline__ void rec2_issue(const SrcJob16& J, const RowSlot& r, int n_mine, int k0, int part, int2& en,
+                                           GatherRec2& g) {
+    const int colm = en.x;
+    const float am = __int_as_float(en.y);
+    const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm);
+    g.a0 = quad_bcast<0>(am); g.a1 = quad_bcast<1>(am);
+    g.q0 = f4zero(); g.g0 = f4zero(); g.s0 = f4zero(); g.q1 = f4zero(); g.g1 = f4zero(); g.s1 = f4zero();
+    g.cc0 = 0.0f; g.cc1 = 0.0f;
+    if (k0 < n_mine) {
+        const float* rr = J.rec + (size_t)c0 * REC_W;
+        g.q0 = ld4(rr + 4 * part); g.g0 = ld4(rr + 16 + 4 * part); g.s0 = ld4(rr + 32); g.cc0 = rr[36];
+    }
+    if (k0 + 1 < n_mine) {
+        const float* rr = J.rec + (size_t)c1 * REC_W;
+        g.q1 = ld4(rr + 4 * part); g.g1 = ld4(rr + 16 + 4 * part); g.s1 = ld4(rr + 32); g.cc1 = rr[36];
+    }
+    const int kn = k0 + 2 + (part & 1);
+    en = kn < n_mine ? J.s.sent[r.first + kn * r.stride] : make_int2(0, 0);
+}
+
+__device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, const float4& xj, int2 en, const RowSlot& rn,
+                                          float4& xjn, int2& enn, int part, int lane, float* merge_lds) {
     const int n_mine = slot_count(r);
-    int2 en = (part & 1) < n_mine ? J.s.sent[r.first + (part & 1) * r.stride] : make_int2(0, 0);
+    float4 acc = f4zero();
     for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
         const int colm = en.x;
         const float am = __int_as_float(en.y);
@@ -914,6 +1030,8 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, i
             fma4(dl, q1, acc);
         }
     }
+    xjn = rn.row >= 0 ? ld4(J.x + (size_t)rn.row * 16 + 4 * part) : f4zero();
+    enn = first_entries<2>(J.s, rn, part);
     if (r.mode >= 1) {
         acc.x = shared_sum4(acc.x, r.mode); acc.y = shared_sum4(acc.y, r.mode);
         acc.z = shared_sum4(acc.z, r.mode); acc.w = shared_sum4(acc.w, r.mode);
@@ -939,11 +1057,25 @@ __global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
     for (int j = 0; j < A.n_jobs; ++j) {
         const SrcJob16& J = A.job[j];
         const PartTiers P = J.s.part[px];
-        for (int k = bi; k < P.n_block; k += gp)
-            src16_row(J, block_slot<4>(J.s, P.row0 + k, tid), part, lane, merge_lds);
+        const RowSlot none = empty_slot();
+        float4 xj, xjn;
+        int2 en, enn;
+        for (int k = bi; k < P.n_block; k += gp) {
+            const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
+            xj = ld4(J.x + (size_t)r.row * 16 + 4 * part);
+            en = first_entries<2>(J.s, r, part);
+            src16_row(J, r, xj, en, none, xjn, enn, part, lane, merge_lds);
+        }
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) src16_row(J, item_slot<4>(J.s, P, it, lane), part, lane, merge_lds);
+        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
+        en = first_entries<2>(J.s, r, part);
+        for (; it < n_items; it += nw) {
+            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
+            src16_row(J, r, xj, en, rn, xjn, enn, part, lane, merge_lds);
+            r = rn; xj = xjn; en = enn;
+        }
         base += n_items;
     }
 }
@@ -1141,22 +1273,22 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
 // ====================================================================================================
 // head backward from given dL/dlogits (caller's variable order): dh3 = dz w_fc (unmasked), fc gradient partials
 // ====================================================================================================
-__global__ __launch_bounds__(FT) void fused_head_bwd_kernel(int n, const float* __restrict__ h3, const float* __restrict__ fcw,
+__global__ __launch_bounds__(RT) void fused_head_bwd_kernel(int n, const float* __restrict__ h3, const float* __restrict__ fcw,
                                                             const float* __restrict__ dlogits, const int* __restrict__ perm,
                                                             float* __restrict__ dh3, float* __restrict__ head_part) {
-    __shared__ float head_lds[FW * 18];
+    __shared__ float head_lds[(RT / 64) * 18];
     const int tid = threadIdx.x, lane = tid & 63, part = lane & 3;
     HeadAcc ha;
     ha.w = f4zero(); ha.b = 0.0f; ha.l = 0.0f;
     const float4 fw = ld4(fcw + 4 * part);
-    for (int row = blockIdx.x * (FT / 4) + (tid >> 2); row < n; row += gridDim.x * (FT / 4)) {
+    for (int row = blockIdx.x * (RT / 4) + (tid >> 2); row < n; row += gridDim.x * (RT / 4)) {
         const float dz = dlogits[perm[row]];
         const float4 hv = ld4(h3 + (size_t)row * 16 + 4 * part);
         *reinterpret_cast<float4*>(dh3 + (size_t)row * 16 + 4 * part) = f4scale(fw, dz);
         fma4(dz, hv, ha.w);
         if (part == 0) ha.b += dz;
     }
-    head_partials_store(ha, head_lds, head_part, tid);
+    head_partials_store<RT / 64>(ha, head_lds, head_part, tid);
 }
 
 // ====================================================================================================
@@ -1172,7 +1304,7 @@ struct ReduceArgs {
     float* loss_out;          // nullable
 };
 
-__global__ __launch_bounds__(FT) void fused_reduce_kernel(ReduceArgs A, int n_conv) {
+__global__ __launch_bounds__(RT) void fused_reduce_kernel(ReduceArgs A, int n_conv) {
     __shared__ float sh[32][32];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == n_conv * STAT_TILES) {     // fc partials: 32 slices x 18 columns
@@ -1398,7 +1530,7 @@ int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t
 
 int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* dlogits, hipStream_t s) {
     const int G = fused_grid(g);
-    hipLaunchKernelGGL(fused_head_bwd_kernel, dim3(G), dim3(FT), 0, s, (int)g->N, m.h3v, m.fcw, dlogits, g->perm_v, m.d3v,
+    hipLaunchKernelGGL(fused_head_bwd_kernel, dim3(G), dim3(RT), 0, s, (int)g->N, m.h3v, m.fcw, dlogits, g->perm_v, m.d3v,
                        m.head_part);
     return check_launch("fused_head_bwd");
 }
@@ -1412,6 +1544,9 @@ static BwdJob16 bwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w
     J.rec = need_rec ? w.rec : nullptr;
     J.dx_dst = dx_dst;
     J.stats = w.stats;
+#ifdef MLLP_TIMING_BUILD
+    J.abl = g_fused_abl;
+#endif
     return J;
 }
 static SrcJob16 src_job16(const FusedOrient& o_src_major, const ConvWs& w, const float* x_rows, float* dx) {
@@ -1452,7 +1587,7 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         SrcLaunch16 S = {};
         S.n_jobs = 1;
         S.job[0] = src_job16(A, m.c[4], m.h2c, m.d2c);
-        hipLaunchKernelGGL(fused_src16_kernel, dim3(G), dim3(FT), 0, s, S);
+        hipLaunchKernelGGL(fused_src16_kernel, dim3(2 * G), dim3(FT), 0, s, S);   // 72 VGPRs: two workgroups per CU
         if ((rc = check_launch("fused_src16 C3"))) return rc;
         BwdLaunch16 L = {};
         L.n_jobs = 1;
@@ -1470,7 +1605,7 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         S.n_jobs = 2;
         S.job[0] = src_job16(A, m.c[2], m.h1c, m.d1c_b);
         S.job[1] = src_job16(At, m.c[3], m.h1v, m.d1v_b);      // K4: C2C source-major (rows = variables)
-        hipLaunchKernelGGL(fused_src16_kernel, dim3(G), dim3(FT), 0, s, S);
+        hipLaunchKernelGGL(fused_src16_kernel, dim3(2 * G), dim3(FT), 0, s, S);   // 72 VGPRs: two workgroups per CU
         if ((rc = check_launch("fused_src16 C2V + C2C"))) return rc;
     }
     {   // K5: layer 1, both convs (inputs are data: no input gradients)
@@ -1488,7 +1623,7 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         R.head_part = m.have_head_part ? m.head_part : nullptr;
         R.head_out = grads + 4704;
         R.loss_out = loss;
-        hipLaunchKernelGGL(fused_reduce_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(FT), 0, s, R, MODEL_CONVS);
+        hipLaunchKernelGGL(fused_reduce_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(RT), 0, s, R, MODEL_CONVS);
         if ((rc = check_launch("fused_reduce"))) return rc;
     }
     {   // K7: the 16x16 algebra of every conv, and the zero gradient of the never-used gconv3_s2w

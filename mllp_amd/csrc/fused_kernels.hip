@@ -46,8 +46,19 @@ static int g_fused_abl = [] {
     return e ? atoi(e) : 0;
 }();
 #define FUSED_ABL(bit) ((J.abl & (bit)) != 0)
+// per-wavefront cycle sums of the segments of fwd16_row (s_memtime), read back by tools/abl_fused.py
+__device__ unsigned long long g_fused_stamps[8192 * 8];
+#define FUSED_STAMP(k)                                                                      \
+    {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        stamp_sum[k] += now_ - stamp_last;                                                  \
+        stamp_last = now_;                                                                  \
+    }
 #else
 #define FUSED_ABL(bit) false
+#define FUSED_STAMP(k)
 #endif
 
 constexpr int FT = 768;             // threads per workgroup of the sweep kernels: 3 wavefronts per SIMD leave 168 VGPRs
@@ -174,6 +185,16 @@ struct RowSlot {
     int mode;     // 0 = row per unit (quad / lane), 1 = row per group of units, 2 = row per wavefront, 3 = per workgroup
     bool writer;  // this unit stores the row's results (and counts it in the statistics)
 };
+// The slot of an item is computed one item ahead (software pipeline below).  Its two row pointers are LOADED and nothing
+// may consume them where they are requested -- hipcc waits for a load in front of its first consumer, and an add right
+// behind the load (first = sptr[row] + q) put `s_waitcnt vmcnt(0)` at the top of every item, which also waited for
+// the prefetches and stores in flight (1.5 k cycles per item in the in-kernel stamps).  SlotReq keeps the raw values;
+// slot_make() turns them into a RowSlot an item later.
+struct SlotReq {
+    int row, q, stride, mode;
+    int sb, se;   // raw loads
+    bool writer;
+};
 // G lanes per unit: 4 (16-channel sweeps: a quad) or 1 (scalar sweeps: a lane)
 template <int G>
 struct Geo {
@@ -186,31 +207,49 @@ __device__ __forceinline__ int wave_items(const PartTiers& s) {
     return s.n_wave + (s.n_group + Geo<G>::RG - 1) / Geo<G>::RG + (s.n_base + Geo<G>::U - 1) / Geo<G>::U;
 }
 template <int G>
-__device__ __forceinline__ RowSlot item_slot(const ItemsDev& S, const PartTiers& s, int item, int lane) {
+__device__ __forceinline__ SlotReq item_request(const ItemsDev& S, const PartTiers& s, int item, int lane) {
     constexpr int U = Geo<G>::U, QG = Geo<G>::QG, RG = Geo<G>::RG;
     const int unit = lane / G;
     const int n_gitems = (s.n_group + RG - 1) / RG;
-    RowSlot r;
-    int q;
+    SlotReq r;
     bool valid;
     if (item < s.n_wave) {
-        r.row = s.row0 + s.n_block + item; q = unit; r.stride = U; r.mode = 2; valid = true; r.writer = unit == 0;
+        r.row = s.row0 + s.n_block + item; r.q = unit; r.stride = U; r.mode = 2; valid = true; r.writer = unit == 0;
     } else if (item < s.n_wave + n_gitems) {
         const int rl = (item - s.n_wave) * RG + unit / QG;
         valid = rl < s.n_group;
-        r.row = s.row0 + s.n_block + s.n_wave + rl; q = unit % QG; r.stride = QG; r.mode = 1; r.writer = valid && q == 0;
+        r.row = s.row0 + s.n_block + s.n_wave + rl; r.q = unit % QG; r.stride = QG; r.mode = 1; r.writer = valid && r.q == 0;
     } else {
         const int rl = (item - s.n_wave - n_gitems) * U + unit;
         valid = rl < s.n_base;
-        r.row = s.row0 + s.n_block + s.n_wave + s.n_group + rl; q = 0; r.stride = 1; r.mode = 0; r.writer = valid;
+        r.row = s.row0 + s.n_block + s.n_wave + s.n_group + rl; r.q = 0; r.stride = 1; r.mode = 0; r.writer = valid;
     }
+    r.sb = 0; r.se = 0;
     if (valid) {
-        r.first = S.sptr[r.row] + q;
-        r.end = S.sptr[r.row + 1];
+        r.sb = S.sptr[r.row];
+        r.se = S.sptr[r.row + 1];
     } else {
-        r.row = -1; r.first = 0; r.end = 0;
+        r.row = -1;
     }
     return r;
+}
+__device__ __forceinline__ SlotReq empty_request() {
+    SlotReq r;
+    r.row = -1; r.q = 0; r.stride = 1; r.mode = 0; r.sb = 0; r.se = 0; r.writer = false;
+    return r;
+}
+__device__ __forceinline__ RowSlot slot_make(const SlotReq& q) {
+    RowSlot r;
+    r.row = q.row; r.first = q.sb + q.q; r.stride = q.stride; r.end = q.se; r.mode = q.mode; r.writer = q.writer;
+    // the two loaded values are taken HERE (requested an item ago: no stall).  Left as aliases of the load's registers
+    // they were first read by the register copies at the loop's back edge, where hipcc can only wait with vmcnt(0):
+    // that also waited for the next item's prefetch, issued moments before (1.3 k cycles per item, in-kernel stamps)
+    asm volatile("" : "+v"(r.first), "+v"(r.end));
+    return r;
+}
+template <int G>
+__device__ __forceinline__ RowSlot item_slot(const ItemsDev& S, const PartTiers& s, int item, int lane) {
+    return slot_make(item_request<G>(S, s, item, lane));
 }
 template <int G>
 __device__ __forceinline__ RowSlot block_slot(const ItemsDev& s, int k, int tid) {     // k: renumbered row id
@@ -274,6 +313,9 @@ struct FwdJob16 {
     float* __restrict__ logits;        // [n_dst] caller's order
     float* __restrict__ g_out;         // [n_dst, 16]  dL/dh of the head, already ReLU-masked
     float* __restrict__ head_part;     // [grid, 18]   {dW_fc[16], db_fc, loss} per workgroup
+#ifdef MLLP_TIMING_BUILD
+    int abl;
+#endif
 };
 struct FwdLaunch16 {
     FwdJob16 job[MAXJOBS];
@@ -355,11 +397,17 @@ struct HeadAcc {
 };
 
 // per-row prologue + sweep + epilogue of one job.  (xd, en): this item's destination row and first entries, fetched
-// while the previous item ran; (rn, xdn, enn): the same for the next item, requested here
-__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const RowSlot& r, const float4& xd, int2 en,
-                                          const RowSlot& rn, float4& xdn, int2& enn, int part,
-                                          int lane, float* merge_lds, float* tiles, HeadAcc& ha) {
-    const int n_mine = slot_count(r);
+// while the previous item ran; they are dead once the sweep is over and receive the same for the next item rn (loading
+// into the SAME registers: a copy of a prefetched value would wait for it right after it was requested)
+__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const RowSlot& r, float4& xd, int2& en,
+                                          int& lrow, const SlotReq& qn, RowSlot& rn, int part,
+                                          int lane, float* merge_lds, float* tiles, HeadAcc& ha
+#ifdef MLLP_TIMING_BUILD
+                                          , unsigned long long (&stamp_sum)[8], unsigned long long& stamp_last
+#endif
+) {
+    FUSED_STAMP(0)      // between items: slot of the next item, loop overhead
+    const int n_mine = FUSED_ABL(256) ? 0 : slot_count(r);
     Gather4 gt;
     gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
     float4 qp;
@@ -368,10 +416,12 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
         float ax_[4];
         tile_put(tiles, xd, lane);
         tile_rows(tiles, lane, ax_);
+        if (!FUSED_ABL(1024))
         tile_put_result(tiles + TILE, mat_apply(ax_, matB_lds(W.BPq, lane), splat4(W.pq0[lane & 15])), lane);
         qp = tile_get(tiles + TILE, lane);
         t = quad_sum(dot4(lds4(W.Pt + 4 * part), xd)) + W.pt0;
     }
+    FUSED_STAMP(1)      // first gathers issued, prologue GEMM
     SoftState st;
     st.Z = f4zero(); st.m = NEG_BIG; st.L = 0.0f; st.u = 0.0f;
     for (int k0 = 0;;) {
@@ -380,9 +430,14 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
         if (!__any(k0 < n_mine)) break;
         gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
     }
+    FUSED_STAMP(2)      // sweep
     // the next item's row and first entries travel while this one finishes
-    xdn = rn.row >= 0 ? ld4(J.x_dst + (size_t)rn.row * 16 + 4 * part) : f4zero();
-    enn = first_entries<4>(J.s, rn, part);
+    const int lrow_cur = lrow;      // where this row's logit goes (caller's variable order), fetched with the row
+    rn = slot_make(qn);             // the next item's row pointers were requested when this item started
+    xd = rn.row >= 0 ? ld4(J.x_dst + (size_t)rn.row * 16 + 4 * part) : f4zero();
+    en = first_entries<4>(J.s, rn, part);
+    lrow = (J.head && rn.row >= 0) ? J.perm[rn.row] : 0;
+    FUSED_STAMP(3)      // prefetch issue
 
     if (r.mode >= 1) soft_merge(st, r.mode);
     if (r.mode == 3) {       // merge the 16 wavefronts of the workgroup through LDS (fixed order)
@@ -418,6 +473,7 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
         tile_rows(tiles, lane, ax_);
         tile_put(tiles + TILE, zn, lane);
         tile_rows(tiles + TILE, lane, az_);
+        if (!FUSED_ABL(512))
         tile_put_result(tiles + 2 * TILE,
                         mat_apply(ax_, matB_lds(W.BWs, lane), mat_apply(az_, matB_lds(W.BWv, lane), splat4(0.0f))), lane);
         o = tile_get(tiles + 2 * TILE, lane);
@@ -426,7 +482,8 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     fma4(S, lds4(W.bv + 4 * part), o);
     fma4(un, lds4(W.we + 4 * part), o);
     const float4 hv = make_float4(fmaxf(o.x, 0.0f), fmaxf(o.y, 0.0f), fmaxf(o.z, 0.0f), fmaxf(o.w, 0.0f));
-    if (writer) {
+    FUSED_STAMP(4)      // merges, epilogue GEMM
+    if (writer && !FUSED_ABL(2048)) {
         *reinterpret_cast<float4*>(J.Z + (size_t)r.row * 16 + 4 * part) = zn;
         if (part == 0) reinterpret_cast<float4*>(J.aux)[r.row] = make_float4(un, st.L > 0.0f ? st.m : 0.0f, rinv, S);
         if (J.head != 2) *reinterpret_cast<float4*>(J.h + (size_t)r.row * 16 + 4 * part) = hv;
@@ -434,7 +491,7 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     if (J.head) {        // fc (16 -> 1) on the conv's output row, reference linear_program_methods.py:250
         const float4 fw = lds4(W.fcw + 4 * part);
         const float z = quad_sum(dot4(hv, fw)) + W.fcb;
-        if (writer && part == 0) J.logits[J.perm[r.row]] = z;
+        if (writer && part == 0) J.logits[lrow_cur] = z;
         if (J.head == 2 && writer) {      // BCEWithLogitsLoss, mean per instance / batch: linear_program_experiment.py:41,139-140
             const float y = J.labels[r.row];
             const float wn = J.inv_n[r.row] * J.inv_batch;
@@ -451,6 +508,7 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
             }
         }
     }
+    FUSED_STAMP(5)      // stores, head
 }
 
 // {dW_fc[16], db, loss} of the workgroup -> head_part[blockIdx][18] (wave order)
@@ -503,6 +561,14 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
     float* tiles = tiles_ + wave * 3 * TILE;
     HeadAcc ha;
     ha.w = f4zero(); ha.b = 0.0f; ha.l = 0.0f;
+#ifdef MLLP_TIMING_BUILD
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_begin = stamp_last;
+#define STAMP_ARGS , stamp_sum, stamp_last
+#else
+#define STAMP_ARGS
+#endif
     // this workgroup's partition of the instances, its rank among the partition's workgroups, their wavefronts
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
     const int gw = bi * FW + wave, nw = gp * FW;
@@ -514,27 +580,39 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
         if (J.head == 2) head_part = J.head_part;
         // block tier: the whole workgroup walks one long row at a time (longest rows first)
         const RowSlot none = empty_slot();
-        float4 xd, xdn;
-        int2 en, enn;
         for (int k = bi; k < P.n_block; k += gp) {
             const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
-            xd = ld4(J.x_dst + (size_t)r.row * 16 + 4 * part);
-            en = first_entries<4>(J.s, r, part);
-            fwd16_row(J, Ws_[j], r, xd, en, none, xdn, enn, part, lane, merge_lds, tiles, ha);
+            float4 xd = ld4(J.x_dst + (size_t)r.row * 16 + 4 * part);
+            int2 en = first_entries<4>(J.s, r, part);
+            int lrow = J.head ? J.perm[r.row] : 0;
+            RowSlot rn;
+            fwd16_row(J, Ws_[j], r, xd, en, lrow, empty_request(), rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
         }
         // wave loop: the items of all jobs form one sequence dealt round-robin over the partition's wavefronts
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
         RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
-        xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
-        en = first_entries<4>(J.s, r, part);
+        float4 xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
+        int2 en = first_entries<4>(J.s, r, part);
+        int lrow = (J.head && r.row >= 0) ? J.perm[r.row] : 0;
         for (; it < n_items; it += nw) {
-            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
-            fwd16_row(J, Ws_[j], r, xd, en, rn, xdn, enn, part, lane, merge_lds, tiles, ha);
-            r = rn; xd = xdn; en = enn;
+            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+            RowSlot rn;
+            fwd16_row(J, Ws_[j], r, xd, en, lrow, qn, rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
+#ifdef MLLP_TIMING_BUILD
+            stamp_sum[7] += 1;      // items
+#endif
+            r = rn;
         }
         base += n_items;
     }
+#ifdef MLLP_TIMING_BUILD
+    if (lane == 0 && A.job[0].abl >= 0) {
+        stamp_sum[6] = __builtin_amdgcn_s_memtime() - stamp_begin;      // whole kernel of this wavefront
+        unsigned long long* d = g_fused_stamps + (size_t)(blockIdx.x * FW + wave) * 8;
+        for (int k = 0; k < 8; ++k) d[k] = stamp_sum[k];
+    }
+#endif
     if (head_part) head_partials_store<FW>(ha, head_lds, head_part, tid);     // (uniform: one job at most has a head)
 }
 
@@ -754,8 +832,8 @@ __device__ __forceinline__ void bwd16_fetch(const BwdJob16& J, const RowSlot& r,
 // tiles of a wavefront in the destination-major backward sweep
 constexpr int TB_G = 0, TB_X = 1, TB_Z = 2, TB_DQ = 3, TB_SC = 4, TB_E = 5, TB_N = 6;
 
-__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, const BwdRow& rd, int2 en,
-                                          const RowSlot& rn, BwdRow& rdn, int2& enn, int part,
+__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, BwdRow& rd, int2& en,
+                                          const SlotReq& qn, RowSlot& rn, int part,
                                           int lane, float* merge_lds, float* tiles, f32x4m (&acc)[STAT_TILES]) {
     const bool have = r.row >= 0;
     const bool writer = r.writer;
@@ -805,8 +883,9 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
     }
     // the next item's row data and first entries travel while this one finishes
-    bwd16_fetch(J, rn, part, rdn);
-    enn = first_entries<4>(J.s, rn, part);
+    rn = slot_make(qn);                // the next item's row pointers were requested when this item started
+    bwd16_fetch(J, rn, part, rd);      // (rd and en are dead here: the next item's data land in the same registers)
+    en = first_entries<4>(J.s, rn, part);
     if (r.mode >= 1) {
         st.ds = shared_sum4(st.ds, r.mode);
         st.dt = shared_sum4(st.dt, r.mode);
@@ -916,23 +995,25 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
 #pragma unroll
         for (int i = 0; i < STAT_TILES; ++i) acc[i] = splat4(0.0f);
         const RowSlot none = empty_slot();
-        BwdRow rd, rdn;
-        int2 en, enn;
         for (int k = bi; k < P.n_block; k += gp) {
             const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
+            BwdRow rd;
             bwd16_fetch(J, r, part, rd);
-            en = first_entries<4>(J.s, r, part);
-            bwd16_row(J, Ws_[j], r, rd, en, none, rdn, enn, part, lane, merge_lds, tiles, acc);
+            int2 en = first_entries<4>(J.s, r, part);
+            RowSlot rn;
+            bwd16_row(J, Ws_[j], r, rd, en, empty_request(), rn, part, lane, merge_lds, tiles, acc);
         }
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
         RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        BwdRow rd;
         bwd16_fetch(J, r, part, rd);
-        en = first_entries<4>(J.s, r, part);
+        int2 en = first_entries<4>(J.s, r, part);
         for (; it < n_items; it += nw) {
-            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
-            bwd16_row(J, Ws_[j], r, rd, en, rn, rdn, enn, part, lane, merge_lds, tiles, acc);
-            r = rn; rd = rdn; en = enn;
+            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+            RowSlot rn;
+            bwd16_row(J, Ws_[j], r, rd, en, qn, rn, part, lane, merge_lds, tiles, acc);
+            r = rn;
         }
         base += n_items;
         // the workgroup's partial statistics: the 16 wavefronts' tiles summed in wave order, one tile at a time
@@ -993,9 +1074,10 @@ __device__ __forceinline__ void rec2_issue(const SrcJob16& J, const RowSlot& r, 
     en = kn < n_mine ? J.s.sent[r.first + kn * r.stride] : make_int2(0, 0);
 }
 
-__device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, const float4& xj, int2 en, const RowSlot& rn,
-                                          float4& xjn, int2& enn, int part, int lane, float* merge_lds) {
+__device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, float4& xj_io, int2& en, const SlotReq& qn,
+                                          RowSlot& rn, int part, int lane, float* merge_lds) {
     const int n_mine = slot_count(r);
+    const float4 xj = xj_io;
     float4 acc = f4zero();
     for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
         const int colm = en.x;
@@ -1030,8 +1112,9 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, c
             fma4(dl, q1, acc);
         }
     }
-    xjn = rn.row >= 0 ? ld4(J.x + (size_t)rn.row * 16 + 4 * part) : f4zero();
-    enn = first_entries<2>(J.s, rn, part);
+    rn = slot_make(qn);
+    xj_io = rn.row >= 0 ? ld4(J.x + (size_t)rn.row * 16 + 4 * part) : f4zero();
+    en = first_entries<2>(J.s, rn, part);
     if (r.mode >= 1) {
         acc.x = shared_sum4(acc.x, r.mode); acc.y = shared_sum4(acc.y, r.mode);
         acc.z = shared_sum4(acc.z, r.mode); acc.w = shared_sum4(acc.w, r.mode);
@@ -1058,23 +1141,23 @@ __global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
         const SrcJob16& J = A.job[j];
         const PartTiers P = J.s.part[px];
         const RowSlot none = empty_slot();
-        float4 xj, xjn;
-        int2 en, enn;
         for (int k = bi; k < P.n_block; k += gp) {
             const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
-            xj = ld4(J.x + (size_t)r.row * 16 + 4 * part);
-            en = first_entries<2>(J.s, r, part);
-            src16_row(J, r, xj, en, none, xjn, enn, part, lane, merge_lds);
+            float4 xj = ld4(J.x + (size_t)r.row * 16 + 4 * part);
+            int2 en = first_entries<2>(J.s, r, part);
+            RowSlot rn;
+            src16_row(J, r, xj, en, empty_request(), rn, part, lane, merge_lds);
         }
         const int n_items = wave_items<4>(P);
         int it = (gw - base % nw + nw) % nw;
         RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
-        xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
-        en = first_entries<2>(J.s, r, part);
+        float4 xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
+        int2 en = first_entries<2>(J.s, r, part);
         for (; it < n_items; it += nw) {
-            const RowSlot rn = it + nw < n_items ? item_slot<4>(J.s, P, it + nw, lane) : none;
-            src16_row(J, r, xj, en, rn, xjn, enn, part, lane, merge_lds);
-            r = rn; xj = xjn; en = enn;
+            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+            RowSlot rn;
+            src16_row(J, r, xj, en, qn, rn, part, lane, merge_lds);
+            r = rn;
         }
         base += n_items;
     }
@@ -1367,6 +1450,12 @@ __global__ void fused_pregather_kernel(int64_t nnz, const int2* __restrict__ sen
     }
 }
 
+#ifdef MLLP_TIMING_BUILD
+extern "C" int mllp_timing_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fused_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, what);
@@ -1391,10 +1480,13 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((int64_t)g->h_csr_ptr.size() != g->M + 1 && !h_csr_ptr) return fail(MLLP_EINVAL, "fused path: no host row pointers");
     HostFusedOrient hc, hv;
     {
-        std::vector<int64_t> inst_nnz((size_t)g->n_inst);
-        for (int64_t k = 0; k < g->n_inst; ++k)
+        std::vector<int64_t> inst_nnz((size_t)g->n_inst), inst_m((size_t)g->n_inst), inst_n((size_t)g->n_inst);
+        for (int64_t k = 0; k < g->n_inst; ++k) {
             inst_nnz[(size_t)k] = (int64_t)h_csr_ptr[g->h_inst_ptr_m[k + 1]] - h_csr_ptr[g->h_inst_ptr_m[k]];
-        const std::vector<int> part = host_partition_instances(inst_nnz, FUSED_PARTS);
+            inst_m[(size_t)k] = g->h_inst_ptr_m[k + 1] - g->h_inst_ptr_m[k];
+            inst_n[(size_t)k] = g->h_inst_ptr_n[k + 1] - g->h_inst_ptr_n[k];
+        }
+        const std::vector<int> part = host_partition_instances(inst_nnz, inst_m, inst_n, FUSED_PARTS);
         host_build_fused_orient(h_csr_ptr, (int)g->M, g->h_inst_ptr_m, part, &hc);     // constraints by (partition, row length)
         host_build_fused_orient(h_csc_ptr, (int)g->N, g->h_inst_ptr_n, part, &hv);     // variables by (partition, column length)
     }
@@ -1477,6 +1569,9 @@ static FwdJob16 fwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.Z = w.Z; J.aux = w.aux;
     J.head = 0;
+#ifdef MLLP_TIMING_BUILD
+    J.abl = g_fused_abl;
+#endif
     return J;
 }
 static FwdJob1 fwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, float* h) {

@@ -134,18 +134,31 @@ void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTier
     t.short_rows = n_dst > 0 && (double)ptr[n_dst] / n_dst <= 16.0;
 }
 
-std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, int n_parts) {
+std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, const std::vector<int64_t>& inst_m,
+                                          const std::vector<int64_t>& inst_n, int n_parts) {
     const int n = (int)inst_nnz.size();
+    constexpr int64_t ROW_W = 12;
+    std::vector<int64_t> ca((size_t)n), cb((size_t)n);
+    int64_t sa = 1, sb = 1;
+    for (int i = 0; i < n; ++i) {
+        ca[i] = ROW_W * inst_m[i] + inst_nnz[i] + 1;      // + 1: empty instances are spread too
+        cb[i] = ROW_W * inst_n[i] + inst_nnz[i] + 1;
+        sa += ca[i]; sb += cb[i];
+    }
     std::vector<int> order((size_t)n), part((size_t)n, 0);
     for (int i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return inst_nnz[a] > inst_nnz[b]; });
-    std::vector<int64_t> load((size_t)n_parts, 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ca[a] + cb[a] > ca[b] + cb[b]; });
+    std::vector<int64_t> la((size_t)n_parts, 0), lb((size_t)n_parts, 0);
     for (int i : order) {
         int best = 0;
-        for (int q = 1; q < n_parts; ++q)
-            if (load[q] < load[best]) best = q;
+        double best_v = 0.0;
+        for (int q = 0; q < n_parts; ++q) {
+            const double v = std::max((double)(la[q] + ca[i]) / (double)sa, (double)(lb[q] + cb[i]) / (double)sb);
+            if (q == 0 || v < best_v) { best = q; best_v = v; }
+        }
         part[i] = best;
-        load[best] += std::max<int64_t>(inst_nnz[i], 1);      // empty instances are spread too
+        la[best] += ca[i];
+        lb[best] += cb[i];
     }
     return part;
 }

@@ -66,10 +66,15 @@ struct HostFusedOrient {
     int row0[FUSED_PARTS + 1];  // first renumbered id of every partition
     FusedTiers t16[FUSED_PARTS], t1[FUSED_PARTS];   // tiers of the 16-channel / 1-channel sweeps inside each partition
 };
-constexpr int FUSED_T16[3] = {16, 64, 1024};     // quad / group (4 quads) / wave (16 quads) / block
-constexpr int FUSED_T1[3] = {16, 256, 4096};     // lane / group (16 lanes) / wave (64 lanes) / block
-// partition of every instance: LPT by nonzeros, ties and order deterministic
-std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, int n_parts);
+constexpr int FUSED_T16[3] = {16, 64, 256};      // quad / group (4 quads) / wave (16 quads) / block: <= 4 steps of 4 nonzeros per quad
+constexpr int FUSED_T1[3] = {16, 128, 1024};     // lane / group (16 lanes) / wave (64 lanes) / block
+// Partition of every instance, deterministic.  A sweep's time in a partition is set by its ITEMS (16 rows each, about
+// 7 k cycles with their first four nonzeros) more than by its nonzeros, and a sweep walks either the constraints or the
+// variables: the greedy rule (largest instance first, to the partition whose worse side stays lowest) balances
+// 12 m + nnz and 12 n + nnz together.  With nonzeros alone the slowest partition of the Netlib batch had 1.7 x the
+// mean number of items and set the time of every kernel.
+std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, const std::vector<int64_t>& inst_m,
+                                          const std::vector<int64_t>& inst_n, int n_parts);
 // inst_off: [n_inst + 1] offsets of the instances' nodes (rows of this orientation)
 void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& inst_off, const std::vector<int>& inst_part,
                              HostFusedOrient* out);

@@ -179,13 +179,23 @@ int main() {
                 check_tiers(b.csc_ptr.data(), (int)b.N, c);
             }
         {
-            std::vector<int64_t> nz(n_inst);
-            for (int k = 0; k < n_inst; ++k) nz[k] = b.csr_ptr[b.pm[k + 1]] - b.csr_ptr[b.pm[k]];
-            const std::vector<int> part = host_partition_instances(nz, FUSED_PARTS);
-            std::vector<int64_t> load(FUSED_PARTS, 0);
-            int64_t mx = 0;
-            for (int k = 0; k < n_inst; ++k) { CHECK(part[k] >= 0 && part[k] < FUSED_PARTS); load[part[k]] += nz[k]; mx = std::max(mx, nz[k]); }
-            for (int q = 0; q < FUSED_PARTS; ++q) CHECK(load[q] <= b.nnz / FUSED_PARTS + mx + n_inst);    // LPT bound
+            std::vector<int64_t> nz(n_inst), mm(n_inst), nn(n_inst);
+            for (int k = 0; k < n_inst; ++k) {
+                nz[k] = b.csr_ptr[b.pm[k + 1]] - b.csr_ptr[b.pm[k]];
+                mm[k] = b.pm[k + 1] - b.pm[k];
+                nn[k] = b.pn[k + 1] - b.pn[k];
+            }
+            const std::vector<int> part = host_partition_instances(nz, mm, nn, FUSED_PARTS);
+            CHECK(part == host_partition_instances(nz, mm, nn, FUSED_PARTS));       // deterministic
+            std::vector<int64_t> la(FUSED_PARTS, 0), lb(FUSED_PARTS, 0);
+            int64_t ma = 0, mb = 0, sa = 0, sb = 0;
+            for (int k = 0; k < n_inst; ++k) {
+                CHECK(part[k] >= 0 && part[k] < FUSED_PARTS);
+                const int64_t ca = 12 * mm[k] + nz[k] + 1, cb = 12 * nn[k] + nz[k] + 1;
+                la[part[k]] += ca; lb[part[k]] += cb; ma = std::max(ma, ca); mb = std::max(mb, cb); sa += ca; sb += cb;
+            }
+            for (int q = 0; q < FUSED_PARTS; ++q)      // greedy bound on both sides (loose: two criteria)
+                CHECK(la[q] <= 2 * (sa / FUSED_PARTS + ma) && lb[q] <= 2 * (sb / FUSED_PARTS + mb));
             check_fused(b.csr_ptr.data(), (int)b.M, b.pm, part);
             check_fused(b.csc_ptr.data(), (int)b.N, b.pn, part);
         }

@@ -197,6 +197,26 @@ int mllp_metrics_scratch_bytes(const mllp_graph_t* g, int64_t* bytes);
 int mllp_topm_metrics(const mllp_graph_t* g, const float* d_logits, const float* d_labels,
                       void* d_scratch, float* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MPS -> the tensors the reference's loader reads (host only, no GPU needed).
+ * Replaces the preprocessing that produced /root/reference/dataset/netlib_mps{,_norm}/<name>_{constrs.npz,
+ * coefs.npy,rhs.npy} from /root/reference/netlib_mps/<name>.mps (input format: afiro.mps:1-83; consumer:
+ * linear_program_data.py:58-80).  The reference ships the tensors but not the script; the rules (recovered from
+ * the data, reproducing all 97 instances) are stated in mllp_amd/csrc/mps_reader.cpp and oracle/mps_norm.py.
+ *   normalize == 0: the raw stage (A, c, b; one extra column per RANGES entry)
+ *   normalize != 0: slack column per L / G row, rows scaled to unit 2-norm with the right-hand side capped at 5,
+ *                   objective scaled to unit 2-norm.
+ * dims[0..5] = m, n (all columns), nnz, structural columns, range columns, slack columns.
+ * mllp_lp_export: any pointer may be null; indptr [m+1] int64, indices [nnz] int32 (ascending in a row),
+ *   values [nnz], coefs [n], rhs [m] float64, slack_rows [slack columns] int32 (the row of each slack, in order:
+ *   basis = [v ; c[slack_rows]] assembles the label vector from a solver's variable / constraint statuses).   */
+typedef struct mllp_lp mllp_lp_t;
+int mllp_mps_read(const char* path, int normalize, mllp_lp_t** out);
+int mllp_lp_dims(const mllp_lp_t* lp, int64_t dims[6]);
+int mllp_lp_export(const mllp_lp_t* lp, int64_t* indptr, int32_t* indices, double* values, double* coefs,
+                   double* rhs, int32_t* slack_rows);
+int mllp_lp_free(mllp_lp_t* lp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ _PROTOTYPES = {
                                c_void_p]),
     "mllp_metrics_scratch_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "mllp_topm_metrics": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mllp_mps_read": (c_int, [c_char_p, c_int, POINTER(c_void_p)]),
+    "mllp_lp_dims": (c_int, [c_void_p, POINTER(c_int64)]),
+    "mllp_lp_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mllp_lp_free": (c_int, [c_void_p]),
 }
 
 _lib = None

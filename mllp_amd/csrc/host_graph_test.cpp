@@ -2,6 +2,7 @@
 // -fsanitize=address,undefined and with -fsanitize=thread; run by tests/test_host_sanitize.py).
 // Random ragged batches (empty rows, empty columns, empty instances, one very long row) through the parallel
 // build with 8 threads; the result is checked against a serial transposition, the row tiers against the rows.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -11,6 +12,11 @@
 #include "host_graph.h"
 
 using namespace mllp;
+
+namespace mllp {
+static std::string g_test_err;
+int fail(int code, const std::string& msg) { g_test_err = msg; return code; }     // the product's is in graph.cpp
+}
 
 #define CHECK(c)                                                        \
     do {                                                                \
@@ -160,7 +166,60 @@ static void check_fused(const int* ptr, int n, const std::vector<int64_t>& off, 
     CHECK(o.sptr[n] == ptr[n]);
 }
 
-int main() {
+// MPS reader under the sanitizers: the committed fixtures (argv) in both stages, and a synthetic file with RANGES on
+// L / G / E rows, a G row, negative right-hand sides, a blank RHS set name, an RHS on the objective and a MARKER line
+static void check_mps(const char* path, bool synthetic) {
+    for (int normalize = 0; normalize < 2; ++normalize) {
+        mllp_lp_t* lp = nullptr;
+        CHECK(mllp_mps_read(path, normalize, &lp) == MLLP_OK);
+        int64_t d[6];
+        CHECK(mllp_lp_dims(lp, d) == MLLP_OK);
+        CHECK(d[0] > 0 && d[1] == d[3] + d[4] + d[5] && (normalize || d[5] == 0));
+        std::vector<int64_t> ip(d[0] + 1);
+        std::vector<int32_t> ix(d[2]), sr(d[5]);
+        std::vector<double> va(d[2]), co(d[1]), rh(d[0]);
+        CHECK(mllp_lp_export(lp, ip.data(), ix.data(), va.data(), co.data(), rh.data(), sr.data()) == MLLP_OK);
+        CHECK(ip[0] == 0 && ip[d[0]] == d[2]);
+        for (int64_t i = 0; i < d[0]; ++i) {
+            double ss = 0.0;
+            for (int64_t e = ip[i]; e < ip[i + 1]; ++e) {
+                CHECK(ix[e] >= 0 && ix[e] < d[1] && (e == ip[i] || ix[e] > ix[e - 1]) && va[e] != 0.0);
+                ss += va[e] * va[e];
+            }
+            if (normalize && ip[i + 1] > ip[i]) {
+                CHECK(std::fabs(rh[i]) <= 5.0 + 1e-12);
+                CHECK(std::fabs(std::sqrt(ss) - 1.0) < 1e-12 || std::fabs(rh[i] - 5.0) < 1e-12);   // unit row or capped rhs
+            }
+        }
+        if (synthetic) {
+            CHECK(d[0] == 5 && d[3] == 3 && d[4] == 3);
+            if (!normalize) { CHECK(rh[0] == -4.0 && rh[1] == 7.0 && rh[3] == 12.0); }
+            else { CHECK(d[5] == 2 && sr[0] == 3 && sr[1] == 4); }
+        }
+        CHECK(mllp_lp_free(lp) == MLLP_OK);
+    }
+}
+
+int main(int argc, char** argv) {
+    for (int a = 1; a < argc; ++a) check_mps(argv[a], false);
+    {
+        const char* path = "/tmp/mllp_sanitize_synth.mps";
+        FILE* fh = std::fopen(path, "w");
+        CHECK(fh != nullptr);
+        std::fputs("NAME          SYNTH\nROWS\n N  COST\n L  R1\n G  R2\n E  R3\n G  R4\n L  R5\n N  FREE\nCOLUMNS\n"
+                   "    MARKER                 'MARKER'                 'INTORG'\n"
+                   "    X1        COST         1.0   R1           2.0\n    X1        R2          -1.5   R4           1.0\n"
+                   "    X2        COST        -2.0   R3           4.0\n    X2        R5           0.5\n"
+                   "    X3        R1           1.0D0 R4          -3.0\n    X3        R5           8.0\n"
+                   "RHS\n    RHS       R1          -4.0   R2           7.0\n              R4          12.0   COST        -9.0\n"
+                   "RANGES\n    RNG       R1           2.0   R2           3.0\n    RNG       R3          -1.0\n"
+                   "BOUNDS\n UP BND       X1           4.0\n FR BND       X2\nENDATA\n", fh);
+        std::fclose(fh);
+        check_mps(path, true);
+        mllp_lp_t* lp = nullptr;
+        CHECK(mllp_mps_read("/nonexistent/file.mps", 1, &lp) == MLLP_EINVAL && lp == nullptr);
+        CHECK(mllp_mps_read(nullptr, 1, &lp) == MLLP_EINVAL);
+    }
     std::mt19937 rng(12345);
     for (int round = 0; round < 6; ++round) {
         const int n_inst = round == 0 ? 1 : 5 + 9 * round;

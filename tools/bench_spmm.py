@@ -5,6 +5,9 @@ import os, sys, time
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("MLLP_TIMING_LIB"):       # experiments: the timing library honours MLLP_TILED_ABLATION
+    from mllp_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", "libmllp_hip_timing.so")
 from mllp_amd.graph import synthetic_batch
 
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -18,7 +21,7 @@ def timed(fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for tr in (False, True):
+for tr in ((False,) if os.environ.get("MLLP_TIMING_LIB") else (False, True)):
     n_in, n_out = (b.M, b.N) if tr else (b.N, b.M)
     H = torch.randn(n_in, 16, device="cuda"); Y = torch.empty(n_out, 16, device="cuda")
     byt = b.nnz * 8 + 4 * (n_out + 1) + n_in * 64 + n_out * 64

@@ -79,11 +79,18 @@ struct ItemsDev {
     const int2* __restrict__ sent;   // [nnz] {source id, value bits}
     const float2* __restrict__ sax;  // [nnz] {a, x_src} (layer 1)
     int n_dst;
+    const int* __restrict__ order;   // [NP][nw][L] items of every wavefront, -1 = none (host_graph.h::HostWaveLists)
+    int nw, L;
     PartTiers part[NP];
 };
 
-static ItemsDev items_dev(const FusedOrient& o, bool scalar) {
+// which == 0: 16-channel lists at one workgroup per CU, 1: 1-channel lists, 2: 16-channel lists at two workgroups per CU
+static ItemsDev items_dev(const FusedOrient& o, int which) {
+    const bool scalar = which == 1;
     ItemsDev d;
+    d.order = which == 0 ? o.lst16 : which == 1 ? o.lst1 : o.lst16x2;
+    d.nw = which == 0 ? o.nw16 : which == 1 ? o.nw1 : o.nw16x2;
+    d.L = which == 0 ? o.L16 : which == 1 ? o.L1 : o.L16x2;
     d.sptr = o.sptr;
     d.sent = reinterpret_cast<const int2*>(o.sent);
     d.sax = reinterpret_cast<const float2*>(o.sax);
@@ -269,6 +276,28 @@ __device__ __forceinline__ RowSlot empty_slot() {
     RowSlot r;
     r.row = -1; r.first = 0; r.stride = 1; r.end = 0; r.mode = 0; r.writer = false;
     return r;
+}
+// The items of one wavefront (static assignment by estimated cost: host_graph.h::HostWaveLists), 64 at a time in a VGPR
+struct WaveList {
+    const int* p;
+    int L, k0, chunk;
+};
+__device__ __forceinline__ WaveList wave_list(const ItemsDev& S, int px, int gw, int lane) {
+    WaveList w;
+    w.L = gw < S.nw ? S.L : 0;
+    w.p = S.order + ((size_t)px * S.nw + gw) * S.L;
+    w.k0 = 0;
+    w.chunk = lane < w.L ? w.p[lane] : -1;
+    return w;
+}
+// k-th item of the wavefront or -1 (k is wave-uniform and only ever grows)
+__device__ __forceinline__ int wave_list_get(WaveList& w, int k, int lane) {
+    if (k >= w.L) return -1;
+    if (k - w.k0 >= 64) {
+        w.k0 = k;
+        w.chunk = k + lane < w.L ? w.p[k + lane] : -1;
+    }
+    return __builtin_amdgcn_readlane(w.chunk, __builtin_amdgcn_readfirstlane(k - w.k0));
 }
 // Software pipeline over the items of a wavefront.  Its memory round trips are what a sweep waits for (PMC of the
 // first version: 69 % of the wave cycles in s_waitcnt at 4 wavefronts per SIMD), so an item's dependent chain
@@ -571,8 +600,7 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
 #endif
     // this workgroup's partition of the instances, its rank among the partition's workgroups, their wavefronts
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
-    const int gw = bi * FW + wave, nw = gp * FW;
-    int base = 0;
+    const int gw = bi * FW + wave;
     float* head_part = nullptr;
     for (int j = 0; j < A.n_jobs; ++j) {
         const FwdJob16& J = A.job[j];
@@ -588,23 +616,24 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
             RowSlot rn;
             fwd16_row(J, Ws_[j], r, xd, en, lrow, empty_request(), rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
         }
-        // wave loop: the items of all jobs form one sequence dealt round-robin over the partition's wavefronts
-        const int n_items = wave_items<4>(P);
-        int it = (gw - base % nw + nw) % nw;
-        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        // wave loop: this wavefront's items (static assignment by estimated cost)
+        WaveList wl = wave_list(J.s, px, gw, lane);
+        int it = wave_list_get(wl, 0, lane);
+        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
         float4 xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
         int2 en = first_entries<4>(J.s, r, part);
         int lrow = (J.head && r.row >= 0) ? J.perm[r.row] : 0;
-        for (; it < n_items; it += nw) {
-            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+        for (int k = 0; it >= 0; ++k) {
+            const int itn = wave_list_get(wl, k + 1, lane);
+            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
             RowSlot rn;
             fwd16_row(J, Ws_[j], r, xd, en, lrow, qn, rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
 #ifdef MLLP_TIMING_BUILD
             stamp_sum[7] += 1;      // items
 #endif
             r = rn;
+            it = itn;
         }
-        base += n_items;
     }
 #ifdef MLLP_TIMING_BUILD
     if (lane == 0 && A.job[0].abl >= 0) {
@@ -741,17 +770,18 @@ __global__ __launch_bounds__(FT) void fused_fwd1_kernel(FwdLaunch1 A) {
     }
     __syncthreads();
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
-    const int gw = bi * FW + wave, nw = gp * FW;
-    int base = 0;
+    const int gw = bi * FW + wave;
     for (int j = 0; j < A.n_jobs; ++j) {
         const FwdJob1& J = A.job[j];
         const PartTiers P = J.s.part[px];
         for (int k = bi; k < P.n_block; k += gp)
             fwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds);
-        const int n_items = wave_items<1>(P);
-        int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
-        base += n_items;
+        WaveList wl = wave_list(J.s, px, gw, lane);
+        for (int k = 0;; ++k) {
+            const int it = wave_list_get(wl, k, lane);
+            if (it < 0) break;
+            fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
+        }
     }
 }
 
@@ -986,8 +1016,7 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
     __syncthreads();
     float* tiles = tiles_ + wave * TB_N * TILE;
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
-    const int gw = bi * FW + wave, nw = gp * FW;
-    int base = 0;
+    const int gw = bi * FW + wave;
     for (int j = 0; j < A.n_jobs; ++j) {
         const BwdJob16& J = A.job[j];
         const PartTiers P = J.s.part[px];
@@ -1003,19 +1032,20 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
             RowSlot rn;
             bwd16_row(J, Ws_[j], r, rd, en, empty_request(), rn, part, lane, merge_lds, tiles, acc);
         }
-        const int n_items = wave_items<4>(P);
-        int it = (gw - base % nw + nw) % nw;
-        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        WaveList wl = wave_list(J.s, px, gw, lane);
+        int it = wave_list_get(wl, 0, lane);
+        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
         BwdRow rd;
         bwd16_fetch(J, r, part, rd);
         int2 en = first_entries<4>(J.s, r, part);
-        for (; it < n_items; it += nw) {
-            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+        for (int k = 0; it >= 0; ++k) {
+            const int itn = wave_list_get(wl, k + 1, lane);
+            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
             RowSlot rn;
             bwd16_row(J, Ws_[j], r, rd, en, qn, rn, part, lane, merge_lds, tiles, acc);
             r = rn;
+            it = itn;
         }
-        base += n_items;
         // the workgroup's partial statistics: the 16 wavefronts' tiles summed in wave order, one tile at a time
         __syncthreads();
         float* red = tiles_;                   // [FW][256]
@@ -1135,8 +1165,7 @@ __global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
     __shared__ float merge_lds[FW * 20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, part = lane & 3;
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
-    const int gw = bi * FW + wave, nw = gp * FW;
-    int base = 0;
+    const int gw = bi * FW + wave;
     for (int j = 0; j < A.n_jobs; ++j) {
         const SrcJob16& J = A.job[j];
         const PartTiers P = J.s.part[px];
@@ -1148,18 +1177,19 @@ __global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
             RowSlot rn;
             src16_row(J, r, xj, en, empty_request(), rn, part, lane, merge_lds);
         }
-        const int n_items = wave_items<4>(P);
-        int it = (gw - base % nw + nw) % nw;
-        RowSlot r = it < n_items ? item_slot<4>(J.s, P, it, lane) : none;
+        WaveList wl = wave_list(J.s, px, gw, lane);
+        int it = wave_list_get(wl, 0, lane);
+        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
         float4 xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
         int2 en = first_entries<2>(J.s, r, part);
-        for (; it < n_items; it += nw) {
-            const SlotReq qn = it + nw < n_items ? item_request<4>(J.s, P, it + nw, lane) : empty_request();
+        for (int k = 0; it >= 0; ++k) {
+            const int itn = wave_list_get(wl, k + 1, lane);
+            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
             RowSlot rn;
             src16_row(J, r, xj, en, qn, rn, part, lane, merge_lds);
             r = rn;
+            it = itn;
         }
-        base += n_items;
     }
 }
 
@@ -1310,8 +1340,7 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
     __syncthreads();
     float* tiles = tiles_ + wave * TILE1;
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
-    const int gw = bi * FW + wave, nw = gp * FW;
-    int base = 0;
+    const int gw = bi * FW + wave;
     for (int j = 0; j < A.n_jobs; ++j) {
         const BwdJob1& J = A.job[j];
         const PartTiers P = J.s.part[px];
@@ -1319,10 +1348,12 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
         float accS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = bi; k < P.n_block; k += gp)
             bwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds, tiles, accT, accS);
-        const int n_items = wave_items<1>(P);
-        int it = (gw - base % nw + nw) % nw;
-        for (; it < n_items; it += nw) bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
-        base += n_items;
+        WaveList wl = wave_list(J.s, px, gw, lane);
+        for (int k = 0;; ++k) {
+            const int it = wave_list_get(wl, k, lane);
+            if (it < 0) break;
+            bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
+        }
         // wavefronts -> workgroup (LDS, wave order), one partial per workgroup in the layout of param_stats1_kernel
         __syncthreads();
         float* red = tiles_;                 // [FW][256 + 6]
@@ -1480,13 +1511,8 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((int64_t)g->h_csr_ptr.size() != g->M + 1 && !h_csr_ptr) return fail(MLLP_EINVAL, "fused path: no host row pointers");
     HostFusedOrient hc, hv;
     {
-        std::vector<int64_t> inst_nnz((size_t)g->n_inst), inst_m((size_t)g->n_inst), inst_n((size_t)g->n_inst);
-        for (int64_t k = 0; k < g->n_inst; ++k) {
-            inst_nnz[(size_t)k] = (int64_t)h_csr_ptr[g->h_inst_ptr_m[k + 1]] - h_csr_ptr[g->h_inst_ptr_m[k]];
-            inst_m[(size_t)k] = g->h_inst_ptr_m[k + 1] - g->h_inst_ptr_m[k];
-            inst_n[(size_t)k] = g->h_inst_ptr_n[k + 1] - g->h_inst_ptr_n[k];
-        }
-        const std::vector<int> part = host_partition_instances(inst_nnz, inst_m, inst_n, FUSED_PARTS);
+        const std::vector<int> part = host_partition_instances(host_instance_cost(h_csr_ptr, g->h_inst_ptr_m),
+                                                               host_instance_cost(h_csc_ptr, g->h_inst_ptr_n), FUSED_PARTS);
         host_build_fused_orient(h_csr_ptr, (int)g->M, g->h_inst_ptr_m, part, &hc);     // constraints by (partition, row length)
         host_build_fused_orient(h_csc_ptr, (int)g->N, g->h_inst_ptr_n, part, &hv);     // variables by (partition, column length)
     }
@@ -1504,6 +1530,24 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
         set_tiers(At.t16[q], hv.t16[q]); set_tiers(At.t1[q], hv.t1[q]);
     }
     for (int q = 0; q <= NP; ++q) { A.row0[q] = hc.row0[q]; At.row0[q] = hv.row0[q]; }
+    {   // items of every wavefront at the grids the sweeps are launched with (fused_grid: fixed per device)
+        const int gp = fused_grid(g) / NP;
+        const HostFusedOrient* ho[2] = {&hc, &hv};
+        FusedOrient* dv[2] = {&A, &At};
+        for (int k = 0; k < 2; ++k) {
+            HostWaveLists l16, l16x2, l1;
+            host_build_wave_lists(*ho[k], false, gp * FW, FW, &l16);
+            host_build_wave_lists(*ho[k], false, 2 * gp * FW, FW, &l16x2);
+            host_build_wave_lists(*ho[k], true, gp * FW, FW, &l1);
+            FusedOrient& d = *dv[k];
+            d.L16 = l16.L; d.nw16 = l16.waves_per_part;
+            d.L16x2 = l16x2.L; d.nw16x2 = l16x2.waves_per_part;
+            d.L1 = l1.L; d.nw1 = l1.waves_per_part;
+            if ((rc = dev_alloc(g, l16.order.size(), &d.lst16, l16.order.data()))) return rc;
+            if ((rc = dev_alloc(g, l16x2.order.size(), &d.lst16x2, l16x2.order.data()))) return rc;
+            if ((rc = dev_alloc(g, l1.order.size(), &d.lst1, l1.order.data()))) return rc;
+        }
+    }
     if ((rc = dev_alloc(g, (size_t)g->M + 1, &A.sptr, hc.sptr.data()))) return rc;
     if ((rc = dev_alloc(g, (size_t)g->N + 1, &At.sptr, hv.sptr.data()))) return rc;
     if ((rc = dev_alloc(g, (size_t)g->nnz * 2, &A.sent))) return rc;
@@ -1565,7 +1609,7 @@ int fused_grid(const mllp_graph* g) { return std::max(std::min(g->n_cu, STAT_BLO
 static FwdJob16 fwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
                           float* h) {
     FwdJob16 J = {};
-    J.s = items_dev(o, false);
+    J.s = items_dev(o, 0);
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.Z = w.Z; J.aux = w.aux;
     J.head = 0;
@@ -1576,7 +1620,7 @@ static FwdJob16 fwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w
 }
 static FwdJob1 fwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, float* h) {
     FwdJob1 J = {};
-    J.s = items_dev(o, true);
+    J.s = items_dev(o, 1);
     J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
     J.h = h; J.Z = w.Z; J.aux = w.aux;
     return J;
@@ -1633,7 +1677,7 @@ int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* d
 static BwdJob16 bwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
                           const float* h, const float* dh_a, const float* dh_b, float* dx_dst, bool need_rec) {
     BwdJob16 J = {};
-    J.s = items_dev(o, false);
+    J.s = items_dev(o, 0);
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux;
     J.rec = need_rec ? w.rec : nullptr;
@@ -1646,14 +1690,14 @@ static BwdJob16 bwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w
 }
 static SrcJob16 src_job16(const FusedOrient& o_src_major, const ConvWs& w, const float* x_rows, float* dx) {
     SrcJob16 J = {};
-    J.s = items_dev(o_src_major, false);
+    J.s = items_dev(o_src_major, 2);
     J.x = x_rows; J.rec = w.rec; J.dx = dx;
     return J;
 }
 static BwdJob1 bwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, const float* h,
                         const float* dh_a, const float* dh_b) {
     BwdJob1 J = {};
-    J.s = items_dev(o, true);
+    J.s = items_dev(o, 1);
     J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
     J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux; J.stats = w.stats;
     return J;

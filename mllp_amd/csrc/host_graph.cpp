@@ -134,15 +134,31 @@ void host_build_tiers(const int* ptr, int n_dst, const TierConfig& cfg, HostTier
     t.short_rows = n_dst > 0 && (double)ptr[n_dst] / n_dst <= 16.0;
 }
 
-std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, const std::vector<int64_t>& inst_m,
-                                          const std::vector<int64_t>& inst_n, int n_parts) {
-    const int n = (int)inst_nnz.size();
-    constexpr int64_t ROW_W = 12;
+std::vector<int64_t> host_instance_cost(const int* ptr, const std::vector<int64_t>& inst_off) {
+    constexpr int64_t ITEM = FUSED_COST_ITEM, STEP = FUSED_COST_STEP;
+    const size_t n = inst_off.empty() ? 0 : inst_off.size() - 1;
+    std::vector<int64_t> cost(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        int64_t c = 0;
+        for (int64_t r = inst_off[k]; r < inst_off[k + 1]; ++r) {
+            const int64_t deg = ptr[r + 1] - ptr[r];
+            if (deg > FUSED_T16[2]) c += 12 * FUSED_COST_BLOCK_ROW;
+            else if (deg > FUSED_T16[1]) c += ITEM + STEP * ((deg + 63) / 64);
+            else if (deg > FUSED_T16[0]) c += (ITEM + STEP * ((deg + 15) / 16)) / 4;
+            else c += (ITEM + STEP * ((deg + 3) / 4)) / 16;
+        }
+        cost[k] = c;
+    }
+    return cost;
+}
+
+std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, const std::vector<int64_t>& cost_b, int n_parts) {
+    const int n = (int)cost_a.size();
     std::vector<int64_t> ca((size_t)n), cb((size_t)n);
     int64_t sa = 1, sb = 1;
     for (int i = 0; i < n; ++i) {
-        ca[i] = ROW_W * inst_m[i] + inst_nnz[i] + 1;      // + 1: empty instances are spread too
-        cb[i] = ROW_W * inst_n[i] + inst_nnz[i] + 1;
+        ca[i] = cost_a[i] + 1;      // + 1: empty instances are spread too
+        cb[i] = cost_b[i] + 1;
         sa += ca[i]; sb += cb[i];
     }
     std::vector<int> order((size_t)n), part((size_t)n, 0);
@@ -195,6 +211,60 @@ void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& 
         }
     }
     for (int q = 0; q < FUSED_PARTS; ++q) o.row0[q + 1] += o.row0[q];
+}
+
+void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, HostWaveLists* out) {
+    HostWaveLists& wl = *out;
+    wl = HostWaveLists();
+    const int nw = std::max(waves_per_part, 1), wpg = std::max(std::min(waves_per_wg, nw), 1), gp = std::max(nw / wpg, 1);
+    wl.waves_per_part = nw;
+    const int U = scalar ? 64 : 16, RG = 4;                  // base rows / group rows per item (fused_kernels.hip::Geo)
+    const int e_base = 4, e_group = 16, e_wave = 64;         // nonzeros of a row per step
+    std::vector<std::vector<int>> lists((size_t)FUSED_PARTS * nw);
+    for (int q = 0; q < FUSED_PARTS; ++q) {
+        const FusedTiers& t = scalar ? o.t1[q] : o.t16[q];
+        const int n_gitems = (t.n_group + RG - 1) / RG, n_bitems = (t.n_base + U - 1) / U;
+        const int n_items = t.n_wave + n_gitems + n_bitems;
+        auto deg_of = [&](int rl) { const int k = o.row0[q] + rl; return (int64_t)o.sptr[(size_t)k + 1] - o.sptr[(size_t)k]; };
+        // cost of every item from its first (longest) row; rows of a tier are sorted by length inside the partition
+        std::vector<std::pair<int64_t, int>> items((size_t)n_items);
+        for (int it = 0; it < n_items; ++it) {
+            int64_t steps;
+            if (it < t.n_wave) steps = (deg_of(t.n_block + it) + e_wave - 1) / e_wave;
+            else if (it < t.n_wave + n_gitems) steps = (deg_of(t.n_block + t.n_wave + (it - t.n_wave) * RG) + e_group - 1) / e_group;
+            else steps = (deg_of(t.n_block + t.n_wave + t.n_group + (it - t.n_wave - n_gitems) * U) + e_base - 1) / e_base;
+            items[(size_t)it] = {FUSED_COST_ITEM + FUSED_COST_STEP * std::max<int64_t>(steps, 1), it};
+        }
+        std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        // Wavefronts of a workgroup do not run equally fast: the SIMD issues its oldest wavefront first, and the stamps
+        // show wavefronts 4-7 of a workgroup taking 7 % and 8-11 taking 19 % longer than 0-3 for the same items.  Each
+        // item goes to the wavefront that would FINISH it first (ties by wavefront id).
+        std::vector<int64_t> load((size_t)nw, 0), slow((size_t)nw, 0);
+        for (int w = 0; w < nw; ++w) {
+            const int bi = w / wpg;
+            const int n_rows = bi < gp && t.n_block > bi ? (t.n_block - bi + gp - 1) / gp : 0;
+            slow[(size_t)w] = 1000 + 95 * ((w % wpg) / 4);          // per mille
+            load[(size_t)w] = FUSED_COST_BLOCK_ROW * n_rows * slow[(size_t)w] / 1000;
+        }
+        for (const auto& itc : items) {
+            int best = 0;
+            int64_t best_t = 0;
+            for (int w = 0; w < nw; ++w) {
+                const int64_t tw = load[(size_t)w] + itc.first * slow[(size_t)w] / 1000;
+                if (w == 0 || tw < best_t) { best = w; best_t = tw; }
+            }
+            lists[(size_t)q * nw + best].push_back(itc.second);
+            load[(size_t)best] = best_t;
+        }
+        for (int w = 0; w < nw; ++w) {
+            wl.max_load = std::max(wl.max_load, load[(size_t)w]);
+            wl.sum_load += load[(size_t)w];
+            wl.L = std::max(wl.L, (int)lists[(size_t)q * nw + w].size());
+        }
+    }
+    wl.L = std::max(wl.L, 1);
+    wl.order.assign((size_t)FUSED_PARTS * nw * wl.L, -1);
+    for (size_t k = 0; k < lists.size(); ++k) std::copy(lists[k].begin(), lists[k].end(), wl.order.begin() + k * wl.L);
 }
 
 }  // namespace mllp

@@ -66,17 +66,40 @@ struct HostFusedOrient {
     int row0[FUSED_PARTS + 1];  // first renumbered id of every partition
     FusedTiers t16[FUSED_PARTS], t1[FUSED_PARTS];   // tiers of the 16-channel / 1-channel sweeps inside each partition
 };
-constexpr int FUSED_T16[3] = {16, 64, 256};      // quad / group (4 quads) / wave (16 quads) / block: <= 4 steps of 4 nonzeros per quad
-constexpr int FUSED_T1[3] = {16, 128, 1024};     // lane / group (16 lanes) / wave (64 lanes) / block
-// Partition of every instance, deterministic.  A sweep's time in a partition is set by its ITEMS (16 rows each, about
-// 7 k cycles with their first four nonzeros) more than by its nonzeros, and a sweep walks either the constraints or the
-// variables: the greedy rule (largest instance first, to the partition whose worse side stays lowest) balances
-// 12 m + nnz and 12 n + nnz together.  With nonzeros alone the slowest partition of the Netlib batch had 1.7 x the
-// mean number of items and set the time of every kernel.
-std::vector<int> host_partition_instances(const std::vector<int64_t>& inst_nnz, const std::vector<int64_t>& inst_m,
-                                          const std::vector<int64_t>& inst_n, int n_parts);
+// quad / group (4 quads) / wave (16 quads) / block.  Every step of a sweep (4 nonzeros per quad) is one round trip
+// to L2, about 2 k cycles whatever its width (in-kernel stamps): a wave-tier row of 1024 nonzeros keeps its wavefront for
+// ~40 k cycles, the whole share of an average wavefront in a Netlib launch, while a block-tier row costs all 12
+// wavefronts of its workgroup ~25 k cycles each (LDS merges, barriers).  (Measured: block tier above 2048 -> the
+// wavefront that drew the longest row ran 116 k cycles and set the launch; above 256 -> 247 block rows.)
+constexpr int FUSED_T16[3] = {16, 64, 1024};
+constexpr int FUSED_T1[3] = {16, 128, 4096};     // lane / group (16 lanes) / wave (64 lanes) / block
+// Cost model of the sweeps, in cycles of one wavefront (stamps of fused_fwd16_kernel on the Netlib batch)
+constexpr int64_t FUSED_COST_ITEM = 5300, FUSED_COST_STEP = 2000, FUSED_COST_BLOCK_ROW = 25000;
+// Estimated cycles of one 16-channel sweep over every instance's rows of one orientation (ptr: row pointers, inst_off:
+// [n_inst + 1] row offsets of the instances): items of 16 base rows, 4 group rows or one wave row; a block row charges
+// every wavefront of a workgroup.
+std::vector<int64_t> host_instance_cost(const int* ptr, const std::vector<int64_t>& inst_off);
+// Partition of every instance, deterministic.  A sweep walks either the constraints or the variables, so the greedy
+// rule (largest instance first, to the partition whose worse side stays lowest) balances the two estimated costs
+// together.  (With nonzeros alone the slowest partition of the Netlib batch had 1.7 x the mean number of items; with
+// 12 rows + nonzeros the tiers were ignored -- a row of 17..64 nonzeros costs four times a row of 16 -- and the
+// slowest partition still ran 1.3 x the mean.)
+std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, const std::vector<int64_t>& cost_b, int n_parts);
 // inst_off: [n_inst + 1] offsets of the instances' nodes (rows of this orientation)
 void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& inst_off, const std::vector<int>& inst_part,
                              HostFusedOrient* out);
+// Which items every wavefront of a sweep works on.  The time of a launch is its slowest wavefront's, and dealing the
+// items round-robin left that one at 1.5 x the mean (group items cost several base items, the workgroups that drew
+// block rows ran 25 k cycles late).  Static longest-processing-time assignment instead (deterministic: the statistics
+// a wavefront accumulates are summed in a fixed order): wavefronts are charged the block rows of their workgroup first
+// (row k of a partition goes to workgroup k mod gp), then every item, heaviest first, goes to the least loaded
+// wavefront of its partition.  order[(q * waves_per_part + w) * L + k] = k-th item of wavefront w of partition q, -1 =
+// none.  `scalar`: the 1-channel geometry (64 base rows / 4 group rows per item) instead of 16 / 4.
+struct HostWaveLists {
+    std::vector<int> order;
+    int L = 0, waves_per_part = 0;
+    int64_t max_load = 0, sum_load = 0;     // of the model, over all wavefronts (informational; tests)
+};
+void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, HostWaveLists* out);
 
 }  // namespace mllp

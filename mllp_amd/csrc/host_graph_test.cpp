@@ -164,6 +164,36 @@ static void check_fused(const int* ptr, int n, const std::vector<int64_t>& off, 
         }
     }
     CHECK(o.sptr[n] == ptr[n]);
+    // wave lists: every item of a partition exactly once, same lists when built again, padded with -1 behind the last
+    for (int scalar = 0; scalar < 2; ++scalar)
+        for (int nw : {1, 12, 36, 384}) {
+            HostWaveLists a, b;
+            host_build_wave_lists(o, scalar != 0, nw, 12, &a);
+            host_build_wave_lists(o, scalar != 0, nw, 12, &b);
+            CHECK(a.order == b.order && a.L == b.L && a.L >= 1 && a.waves_per_part == nw);
+            CHECK(a.order.size() == (size_t)FUSED_PARTS * nw * a.L);
+            CHECK(a.max_load * (int64_t)FUSED_PARTS * nw >= a.sum_load);
+            for (int q = 0; q < FUSED_PARTS; ++q) {
+                const FusedTiers& t = scalar ? o.t1[q] : o.t16[q];
+                const int n_items = t.n_wave + (t.n_group + 3) / 4 + (t.n_base + (scalar ? 63 : 15)) / (scalar ? 64 : 16);
+                std::vector<int> seen(n_items, 0);
+                size_t longest = 0;
+                for (int w = 0; w < nw; ++w) {
+                    bool ended = false;
+                    size_t len = 0;
+                    for (int k = 0; k < a.L; ++k) {
+                        const int it = a.order[((size_t)q * nw + w) * a.L + k];
+                        if (it < 0) { ended = true; continue; }
+                        CHECK(!ended && it < n_items);
+                        seen[it]++;
+                        len++;
+                    }
+                    longest = std::max(longest, len);
+                }
+                for (int it = 0; it < n_items; ++it) CHECK(seen[it] == 1);
+                CHECK(longest <= (size_t)a.L);
+            }
+        }
 }
 
 // MPS reader under the sanitizers: the committed fixtures (argv) in both stages, and a synthetic file with RANGES on
@@ -238,19 +268,15 @@ int main(int argc, char** argv) {
                 check_tiers(b.csc_ptr.data(), (int)b.N, c);
             }
         {
-            std::vector<int64_t> nz(n_inst), mm(n_inst), nn(n_inst);
-            for (int k = 0; k < n_inst; ++k) {
-                nz[k] = b.csr_ptr[b.pm[k + 1]] - b.csr_ptr[b.pm[k]];
-                mm[k] = b.pm[k + 1] - b.pm[k];
-                nn[k] = b.pn[k + 1] - b.pn[k];
-            }
-            const std::vector<int> part = host_partition_instances(nz, mm, nn, FUSED_PARTS);
-            CHECK(part == host_partition_instances(nz, mm, nn, FUSED_PARTS));       // deterministic
+            const std::vector<int64_t> ka = host_instance_cost(b.csr_ptr.data(), b.pm), kb = host_instance_cost(b.csc_ptr.data(), b.pn);
+            CHECK((int)ka.size() == n_inst && (int)kb.size() == n_inst);
+            const std::vector<int> part = host_partition_instances(ka, kb, FUSED_PARTS);
+            CHECK(part == host_partition_instances(ka, kb, FUSED_PARTS));       // deterministic
             std::vector<int64_t> la(FUSED_PARTS, 0), lb(FUSED_PARTS, 0);
             int64_t ma = 0, mb = 0, sa = 0, sb = 0;
             for (int k = 0; k < n_inst; ++k) {
-                CHECK(part[k] >= 0 && part[k] < FUSED_PARTS);
-                const int64_t ca = 12 * mm[k] + nz[k] + 1, cb = 12 * nn[k] + nz[k] + 1;
+                CHECK(part[k] >= 0 && part[k] < FUSED_PARTS && ka[k] >= 0 && kb[k] >= 0);
+                const int64_t ca = ka[k] + 1, cb = kb[k] + 1;
                 la[part[k]] += ca; lb[part[k]] += cb; ma = std::max(ma, ca); mb = std::max(mb, cb); sa += ca; sb += cb;
             }
             for (int q = 0; q < FUSED_PARTS; ++q)      // greedy bound on both sides (loose: two criteria)

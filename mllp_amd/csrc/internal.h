@@ -72,6 +72,10 @@ struct FusedOrient {
     float* sax = nullptr;       // [nnz][2] {a_ij, x_src} of the bound layer-1 inputs (scalar node features are data)
     int row0[FUSED_NP + 1] = {};
     FusedTiersDev t16[FUSED_NP], t1[FUSED_NP];
+    // items of every wavefront (host_graph.h::HostWaveLists), [FUSED_NP][nw][L]: 16-channel sweeps at one workgroup per
+    // CU (lst16) and at two (lst16x2: fused_src16_kernel), 1-channel sweeps (lst1)
+    int* lst16 = nullptr; int* lst16x2 = nullptr; int* lst1 = nullptr;
+    int L16 = 0, L16x2 = 0, L1 = 0, nw16 = 0, nw16x2 = 0, nw1 = 0;
 };
 constexpr int SCRATCH_NS = 20;  // floats per partial-state slot of a split row
 

@@ -43,3 +43,14 @@ print(f"fwd16 layer 3: {int(items)} items, {a[:, 6].mean():.0f} cycles per wavef
 for k, nm in enumerate(names):
     print(f"   {nm:34s} {a[:, k].sum() / items:8.0f} cycles")
 print(f"   {'sum':34s} {a[:, :6].sum() / items:8.0f} cycles;  items per wavefront mean {a[:,7].mean():.2f} max {a[:,7].max():.0f}")
+
+# where the slowest wavefronts are: per workgroup (blockIdx = bi * 8 + partition), max and mean over its 12 wavefronts
+w = a[:, 6].reshape(-1, 12)
+n_wg = w.shape[0]
+print("per-partition workgroup totals (k cycles): columns = rank bi of the workgroup inside its partition")
+for px in range(8):
+    mx = w[px::8].max(1) / 1e3
+    print(f"  part {px}: max-wave per WG:", " ".join(f"{v:4.0f}" for v in mx[:40]))
+it = a[:, 7].reshape(-1, 12)
+print("items per wavefront, partition 0, first 6 WGs:", it[0:48:8].astype(int).tolist())
+print("cycles per wavefront, partition 0, first 6 WGs (k):", (w[0:48:8] / 1e3).round(0).astype(int).tolist())

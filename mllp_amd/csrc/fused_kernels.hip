@@ -78,7 +78,7 @@ struct ItemsDev {
     const int* __restrict__ sptr;    // [n_dst + 1]
     const int2* __restrict__ sent;   // [nnz] {source id, value bits}
     const float2* __restrict__ sax;  // [nnz] {a, x_src} (layer 1)
-    int n_dst;
+    int n_dst, nnz;
     const int* __restrict__ order;   // [NP][nw][L] items of every wavefront, -1 = none (host_graph.h::HostWaveLists)
     int nw, L;
     PartTiers part[NP];
@@ -95,6 +95,7 @@ static ItemsDev items_dev(const FusedOrient& o, int which) {
     d.sent = reinterpret_cast<const int2*>(o.sent);
     d.sax = reinterpret_cast<const float2*>(o.sax);
     d.n_dst = o.n_dst;
+    d.nnz = o.nnz;
     for (int q = 0; q < NP; ++q) {
         const FusedTiersDev& t = scalar ? o.t1[q] : o.t16[q];
         d.part[q].row0 = o.row0[q];
@@ -231,13 +232,13 @@ __device__ __forceinline__ SlotReq item_request(const ItemsDev& S, const PartTie
         valid = rl < s.n_base;
         r.row = s.row0 + s.n_block + s.n_wave + s.n_group + rl; r.q = 0; r.stride = 1; r.mode = 0; r.writer = valid;
     }
-    r.sb = 0; r.se = 0;
-    if (valid) {
-        r.sb = S.sptr[r.row];
-        r.se = S.sptr[r.row + 1];
-    } else {
-        r.row = -1;
-    }
+    // unconditional loads (row 0 for a unit without a row): a load under `if (valid)` is merged with the other path's
+    // constant by a register COPY right behind the load, and hipcc waits for the load there (vmcnt(0), a full round trip
+    // at the spot where the request was meant to leave and be forgotten)
+    const int rc = valid ? r.row : 0;
+    r.sb = S.sptr[rc];
+    r.se = S.sptr[rc + 1];
+    if (!valid) r.row = -1;
     return r;
 }
 __device__ __forceinline__ SlotReq empty_request() {
@@ -247,7 +248,7 @@ __device__ __forceinline__ SlotReq empty_request() {
 }
 __device__ __forceinline__ RowSlot slot_make(const SlotReq& q) {
     RowSlot r;
-    r.row = q.row; r.first = q.sb + q.q; r.stride = q.stride; r.end = q.se; r.mode = q.mode; r.writer = q.writer;
+    r.row = q.row; r.first = q.sb + q.q; r.stride = q.stride; r.end = q.row >= 0 ? q.se : 0; r.mode = q.mode; r.writer = q.writer;
     // the two loaded values are taken HERE (requested an item ago: no stall).  Left as aliases of the load's registers
     // they were first read by the register copies at the loop's back edge, where hipcc can only wait with vmcnt(0):
     // that also waited for the next item's prefetch, issued moments before (1.3 k cycles per item, in-kernel stamps)
@@ -277,27 +278,30 @@ __device__ __forceinline__ RowSlot empty_slot() {
     r.row = -1; r.first = 0; r.stride = 1; r.end = 0; r.mode = 0; r.writer = false;
     return r;
 }
-// The items of one wavefront (static assignment by estimated cost: host_graph.h::HostWaveLists), 64 at a time in a VGPR
+// The items of one wavefront (static assignment by estimated cost: host_graph.h::HostWaveLists), 64 at a time in a
+// VGPR.  A chunk is loaded and WAITED FOR outside the item loop (wave_list_chunk): with the reload inside the loop
+// hipcc put `s_waitcnt vmcnt(0)` in front of every v_readlane, which also waited for the stores of the item before
+// (1.3 k cycles per item in the stamps).  The item pipelines drain at a chunk's end (one cold start per 64 items).
 struct WaveList {
     const int* p;
-    int L, k0, chunk;
+    int L, chunk;
 };
-__device__ __forceinline__ WaveList wave_list(const ItemsDev& S, int px, int gw, int lane) {
+__device__ __forceinline__ WaveList wave_list(const ItemsDev& S, int px, int gw) {
     WaveList w;
     w.L = gw < S.nw ? S.L : 0;
     w.p = S.order + ((size_t)px * S.nw + gw) * S.L;
-    w.k0 = 0;
-    w.chunk = lane < w.L ? w.p[lane] : -1;
+    w.chunk = -1;
     return w;
 }
-// k-th item of the wavefront or -1 (k is wave-uniform and only ever grows)
-__device__ __forceinline__ int wave_list_get(WaveList& w, int k, int lane) {
-    if (k >= w.L) return -1;
-    if (k - w.k0 >= 64) {
-        w.k0 = k;
-        w.chunk = k + lane < w.L ? w.p[k + lane] : -1;
-    }
-    return __builtin_amdgcn_readlane(w.chunk, __builtin_amdgcn_readfirstlane(k - w.k0));
+// items c0 .. c0 + 63 of the list
+__device__ __forceinline__ void wave_list_chunk(WaveList& w, int c0, int lane) {
+    int v = c0 + lane < w.L ? w.p[c0 + lane] : -1;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));      // taken here, not at the first v_readlane of the item loop
+    w.chunk = v;
+}
+// k-th item of the current chunk or -1 (k is wave-uniform)
+__device__ __forceinline__ int wave_list_get(const WaveList& w, int k) {
+    return k < 64 ? __builtin_amdgcn_readlane(w.chunk, __builtin_amdgcn_readfirstlane(k)) : -1;
 }
 // Software pipeline over the items of a wavefront.  Its memory round trips are what a sweep waits for (PMC of the
 // first version: 69 % of the wave cycles in s_waitcnt at 4 wavefronts per SIMD), so an item's dependent chain
@@ -309,6 +313,13 @@ template <int LPE>
 __device__ __forceinline__ int2 first_entries(const ItemsDev& s, const RowSlot& r, int part) {
     const int k = LPE == 4 ? part : (part & 1);
     return k < slot_count(r) ? s.sent[r.first + k * r.stride] : make_int2(0, 0);
+}
+// the same without a branch around the load (see item_request): lanes without an entry read a valid index and their
+// value is never used (the sweeps test k < slot_count before they use an entry)
+template <int LPE>
+__device__ __forceinline__ int2 first_entries_any(const ItemsDev& s, const RowSlot& r, int part) {
+    const int k = LPE == 4 ? part : (part & 1);
+    return s.sent[max(min(r.first + k * r.stride, s.nnz - 1), 0)];
 }
 // sums / maxima over the units that share a row (quad layout: values replicated inside a quad or owned per part)
 __device__ __forceinline__ float shared_sum4(float v, int mode) {
@@ -425,12 +436,41 @@ struct HeadAcc {
     float b, l;    // db_fc, loss (part-0 lanes)
 };
 
-// per-row prologue + sweep + epilogue of one job.  (xd, en): this item's destination row and first entries, fetched
-// while the previous item ran; they are dead once the sweep is over and receive the same for the next item rn (loading
-// into the SAME registers: a copy of a prefetched value would wait for it right after it was requested)
-__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const RowSlot& r, float4& xd, int2& en,
-                                          int& lrow, const SlotReq& qn, RowSlot& rn, int part,
-                                          int lane, float* merge_lds, float* tiles, HeadAcc& ha
+// Results of an item, stored one item LATER (after the next item's sweep).  Stored at the item's end they were still
+// on their way at the loop's back edge, where the first use of the prefetched row data makes hipcc wait with vmcnt(0)
+// -- 1.3-1.6 k cycles per item waiting for store acknowledgements (in-kernel stamps, "between items").
+struct FwdPending {
+    float4 zn, hv, g, aux;
+    float z;
+    int row, lrow;      // row < 0: nothing pending
+};
+__device__ __forceinline__ void fwd16_flush(const FwdJob16& J, FwdPending& p, int part) {
+    if (p.row >= 0 && !FUSED_ABL(2048)) {
+        *reinterpret_cast<float4*>(J.Z + (size_t)p.row * 16 + 4 * part) = p.zn;
+        if (part == 0) reinterpret_cast<float4*>(J.aux)[p.row] = p.aux;
+        if (J.head != 2) *reinterpret_cast<float4*>(J.h + (size_t)p.row * 16 + 4 * part) = p.hv;
+        if (J.head && part == 0) J.logits[p.lrow] = p.z;
+        if (J.head == 2) *reinterpret_cast<float4*>(J.g_out + (size_t)p.row * 16 + 4 * part) = p.g;
+    }
+    p.row = -1;
+}
+
+// per-row prologue + sweep + epilogue of one job.  Two-deep pipeline over a wavefront's items: every item costs two
+// DEPENDENT round trips (row pointers -> first entries / row data), about 2.5 k cycles each, and with the second one
+// requested behind the sweep an item waited ~1.5 k cycles for it at its start (in-kernel stamps, "between items").
+// Now item i, right behind its own first gathers, turns the row pointers of item i + 1 (requested during item i - 1:
+// q1) into that item's slot and requests its row data and first entries (nx), and requests the row pointers of item
+// i + 2 (it2): both round trips have a whole item to complete.
+struct FwdNext {
+    RowSlot r;
+    float4 xd;
+    int2 en;
+    int lrow;
+    SlotReq q;      // row pointers of the item after the next
+};
+__device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, const PartTiers& P, const RowSlot& r,
+                                          const float4& xd, int2& en, int lrow, const SlotReq& q1, int it2, FwdNext& nx,
+                                          FwdPending& pend, int part, int lane, float* merge_lds, float* tiles, HeadAcc& ha
 #ifdef MLLP_TIMING_BUILD
                                           , unsigned long long (&stamp_sum)[8], unsigned long long& stamp_last
 #endif
@@ -439,6 +479,11 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     const int n_mine = FUSED_ABL(256) ? 0 : slot_count(r);
     Gather4 gt;
     gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
+    nx.r = slot_make(q1);
+    nx.xd = ld4(J.x_dst + (size_t)max(nx.r.row, 0) * 16 + 4 * part);      // row 0 for a quad without a row: never stored
+    nx.en = first_entries_any<4>(J.s, nx.r, part);
+    nx.lrow = J.perm[max(nx.r.row, 0)];
+    nx.q = item_request<4>(J.s, P, max(it2, 0), lane);                     // it2 < 0: the item loop ends before it is used
     float4 qp;
     float t;
     {   // q' = Pq x + pq0 on the MFMA (rows of the wavefront through tile 0, kept for the epilogue; result through tile 1)
@@ -460,12 +505,13 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
         gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
     }
     FUSED_STAMP(2)      // sweep
-    // the next item's row and first entries travel while this one finishes
+    // The sweep's last wait for gathers has just drained the memory pipe: the next item's data (requested at this item's
+    // start) is TAKEN here, where waiting is free.  Left pending, hipcc waits for it at the register copies of the loop's
+    // back edge with vmcnt(0), which also waits for the stores below (1.3 k cycles per item in the stamps).
+    asm volatile("" : "+v"(nx.xd.x), "+v"(nx.xd.y), "+v"(nx.xd.z), "+v"(nx.xd.w), "+v"(nx.en.x), "+v"(nx.en.y),
+                      "+v"(nx.lrow), "+v"(nx.q.sb), "+v"(nx.q.se));
+    fwd16_flush(J, pend, part);     // the previous item's results leave now: acknowledged long before the back edge
     const int lrow_cur = lrow;      // where this row's logit goes (caller's variable order), fetched with the row
-    rn = slot_make(qn);             // the next item's row pointers were requested when this item started
-    xd = rn.row >= 0 ? ld4(J.x_dst + (size_t)rn.row * 16 + 4 * part) : f4zero();
-    en = first_entries<4>(J.s, rn, part);
-    lrow = (J.head && rn.row >= 0) ? J.perm[rn.row] : 0;
     FUSED_STAMP(3)      // prefetch issue
 
     if (r.mode >= 1) soft_merge(st, r.mode);
@@ -512,24 +558,22 @@ __device__ __forceinline__ void fwd16_row(const FwdJob16& J, const FwdW16& W, co
     fma4(un, lds4(W.we + 4 * part), o);
     const float4 hv = make_float4(fmaxf(o.x, 0.0f), fmaxf(o.y, 0.0f), fmaxf(o.z, 0.0f), fmaxf(o.w, 0.0f));
     FUSED_STAMP(4)      // merges, epilogue GEMM
-    if (writer && !FUSED_ABL(2048)) {
-        *reinterpret_cast<float4*>(J.Z + (size_t)r.row * 16 + 4 * part) = zn;
-        if (part == 0) reinterpret_cast<float4*>(J.aux)[r.row] = make_float4(un, st.L > 0.0f ? st.m : 0.0f, rinv, S);
-        if (J.head != 2) *reinterpret_cast<float4*>(J.h + (size_t)r.row * 16 + 4 * part) = hv;
-    }
+    pend.row = writer ? r.row : -1;
+    pend.zn = zn; pend.hv = hv; pend.lrow = lrow_cur;
+    pend.aux = make_float4(un, st.L > 0.0f ? st.m : 0.0f, rinv, S);
+    pend.z = 0.0f; pend.g = f4zero();
     if (J.head) {        // fc (16 -> 1) on the conv's output row, reference linear_program_methods.py:250
         const float4 fw = lds4(W.fcw + 4 * part);
         const float z = quad_sum(dot4(hv, fw)) + W.fcb;
-        if (writer && part == 0) J.logits[lrow_cur] = z;
+        pend.z = z;
         if (J.head == 2 && writer) {      // BCEWithLogitsLoss, mean per instance / batch: linear_program_experiment.py:41,139-140
             const float y = J.labels[r.row];
             const float wn = J.inv_n[r.row] * J.inv_batch;
             const float e = expf(-fabsf(z));
             const float sig = z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
             const float dz = wn * (sig - y);
-            const float4 g = make_float4(hv.x > 0.0f ? dz * fw.x : 0.0f, hv.y > 0.0f ? dz * fw.y : 0.0f,
-                                         hv.z > 0.0f ? dz * fw.z : 0.0f, hv.w > 0.0f ? dz * fw.w : 0.0f);
-            *reinterpret_cast<float4*>(J.g_out + (size_t)r.row * 16 + 4 * part) = g;
+            pend.g = make_float4(hv.x > 0.0f ? dz * fw.x : 0.0f, hv.y > 0.0f ? dz * fw.y : 0.0f,
+                                 hv.z > 0.0f ? dz * fw.z : 0.0f, hv.w > 0.0f ? dz * fw.w : 0.0f);
             fma4(dz, hv, ha.w);
             if (part == 0) {
                 ha.b += dz;
@@ -608,32 +652,43 @@ __global__ __launch_bounds__(FT) void fused_fwd16_kernel(FwdLaunch16 A) {
         if (J.head == 2) head_part = J.head_part;
         // block tier: the whole workgroup walks one long row at a time (longest rows first)
         const RowSlot none = empty_slot();
+        FwdPending pend;
+        pend.row = -1;
         for (int k = bi; k < P.n_block; k += gp) {
             const RowSlot r = block_slot<4>(J.s, P.row0 + k, tid);
-            float4 xd = ld4(J.x_dst + (size_t)r.row * 16 + 4 * part);
+            const float4 xd = ld4(J.x_dst + (size_t)r.row * 16 + 4 * part);
             int2 en = first_entries<4>(J.s, r, part);
-            int lrow = J.head ? J.perm[r.row] : 0;
-            RowSlot rn;
-            fwd16_row(J, Ws_[j], r, xd, en, lrow, empty_request(), rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
+            const int lrow = J.head ? J.perm[r.row] : 0;
+            FwdNext nx;
+            fwd16_row(J, Ws_[j], P, r, xd, en, lrow, empty_request(), -1, nx, pend, part, lane, merge_lds, tiles, ha STAMP_ARGS);
         }
         // wave loop: this wavefront's items (static assignment by estimated cost)
-        WaveList wl = wave_list(J.s, px, gw, lane);
-        int it = wave_list_get(wl, 0, lane);
-        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
-        float4 xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
-        int2 en = first_entries<4>(J.s, r, part);
-        int lrow = (J.head && r.row >= 0) ? J.perm[r.row] : 0;
-        for (int k = 0; it >= 0; ++k) {
-            const int itn = wave_list_get(wl, k + 1, lane);
-            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
-            RowSlot rn;
-            fwd16_row(J, Ws_[j], r, xd, en, lrow, qn, rn, part, lane, merge_lds, tiles, ha STAMP_ARGS);
+        WaveList wl = wave_list(J.s, px, gw);
+        for (int c0 = 0; c0 < wl.L; c0 += 64) {
+            wave_list_chunk(wl, c0, lane);
+            int it = wave_list_get(wl, 0), it1 = wave_list_get(wl, 1);
+            RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
+            float4 xd = r.row >= 0 ? ld4(J.x_dst + (size_t)r.row * 16 + 4 * part) : f4zero();
+            int2 en = first_entries<4>(J.s, r, part);
+            int lrow = (J.head && r.row >= 0) ? J.perm[r.row] : 0;
+            SlotReq q1 = item_request<4>(J.s, P, max(it1, 0), lane);
+            if (it1 < 0) q1.row = -1;
+            // cold start: everything requested above is waited for HERE -- left pending into the loop, the copies at its
+            // header would wait with vmcnt(0) in every iteration (the waits of a loop header cover its entry path too)
+            asm volatile("" : "+v"(xd.x), "+v"(xd.y), "+v"(xd.z), "+v"(xd.w), "+v"(en.x), "+v"(en.y), "+v"(lrow),
+                              "+v"(q1.sb), "+v"(q1.se));
+            for (int k = 0; it >= 0; ++k) {
+                const int it2 = wave_list_get(wl, k + 2);
+                FwdNext nx;
+                fwd16_row(J, Ws_[j], P, r, xd, en, lrow, q1, it2, nx, pend, part, lane, merge_lds, tiles, ha STAMP_ARGS);
 #ifdef MLLP_TIMING_BUILD
-            stamp_sum[7] += 1;      // items
+                stamp_sum[7] += 1;      // items
 #endif
-            r = rn;
-            it = itn;
+                r = nx.r; xd = nx.xd; en = nx.en; lrow = nx.lrow; q1 = nx.q;
+                it = it1; it1 = it2;
+            }
         }
+        fwd16_flush(J, pend, part);
     }
 #ifdef MLLP_TIMING_BUILD
     if (lane == 0 && A.job[0].abl >= 0) {
@@ -776,11 +831,14 @@ __global__ __launch_bounds__(FT) void fused_fwd1_kernel(FwdLaunch1 A) {
         const PartTiers P = J.s.part[px];
         for (int k = bi; k < P.n_block; k += gp)
             fwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds);
-        WaveList wl = wave_list(J.s, px, gw, lane);
-        for (int k = 0;; ++k) {
-            const int it = wave_list_get(wl, k, lane);
-            if (it < 0) break;
-            fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
+        WaveList wl = wave_list(J.s, px, gw);
+        for (int c0 = 0; c0 < wl.L; c0 += 64) {
+            wave_list_chunk(wl, c0, lane);
+            for (int k = 0;; ++k) {
+                const int it = wave_list_get(wl, k);
+                if (it < 0) break;
+                fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
+            }
         }
     }
 }
@@ -1032,19 +1090,22 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
             RowSlot rn;
             bwd16_row(J, Ws_[j], r, rd, en, empty_request(), rn, part, lane, merge_lds, tiles, acc);
         }
-        WaveList wl = wave_list(J.s, px, gw, lane);
-        int it = wave_list_get(wl, 0, lane);
-        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
-        BwdRow rd;
-        bwd16_fetch(J, r, part, rd);
-        int2 en = first_entries<4>(J.s, r, part);
-        for (int k = 0; it >= 0; ++k) {
-            const int itn = wave_list_get(wl, k + 1, lane);
-            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
-            RowSlot rn;
-            bwd16_row(J, Ws_[j], r, rd, en, qn, rn, part, lane, merge_lds, tiles, acc);
-            r = rn;
-            it = itn;
+        WaveList wl = wave_list(J.s, px, gw);
+        for (int c0 = 0; c0 < wl.L; c0 += 64) {
+            wave_list_chunk(wl, c0, lane);
+            int it = wave_list_get(wl, 0);
+            RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
+            BwdRow rd;
+            bwd16_fetch(J, r, part, rd);
+            int2 en = first_entries<4>(J.s, r, part);
+            for (int k = 0; it >= 0; ++k) {
+                const int itn = wave_list_get(wl, k + 1);
+                const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
+                RowSlot rn;
+                bwd16_row(J, Ws_[j], r, rd, en, qn, rn, part, lane, merge_lds, tiles, acc);
+                r = rn;
+                it = itn;
+            }
         }
         // the workgroup's partial statistics: the 16 wavefronts' tiles summed in wave order, one tile at a time
         __syncthreads();
@@ -1177,18 +1238,21 @@ __global__ __launch_bounds__(FT) void fused_src16_kernel(SrcLaunch16 A) {
             RowSlot rn;
             src16_row(J, r, xj, en, empty_request(), rn, part, lane, merge_lds);
         }
-        WaveList wl = wave_list(J.s, px, gw, lane);
-        int it = wave_list_get(wl, 0, lane);
-        RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
-        float4 xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
-        int2 en = first_entries<2>(J.s, r, part);
-        for (int k = 0; it >= 0; ++k) {
-            const int itn = wave_list_get(wl, k + 1, lane);
-            const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
-            RowSlot rn;
-            src16_row(J, r, xj, en, qn, rn, part, lane, merge_lds);
-            r = rn;
-            it = itn;
+        WaveList wl = wave_list(J.s, px, gw);
+        for (int c0 = 0; c0 < wl.L; c0 += 64) {
+            wave_list_chunk(wl, c0, lane);
+            int it = wave_list_get(wl, 0);
+            RowSlot r = it >= 0 ? item_slot<4>(J.s, P, it, lane) : none;
+            float4 xj = r.row >= 0 ? ld4(J.x + (size_t)r.row * 16 + 4 * part) : f4zero();
+            int2 en = first_entries<2>(J.s, r, part);
+            for (int k = 0; it >= 0; ++k) {
+                const int itn = wave_list_get(wl, k + 1);
+                const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
+                RowSlot rn;
+                src16_row(J, r, xj, en, qn, rn, part, lane, merge_lds);
+                r = rn;
+                it = itn;
+            }
         }
     }
 }
@@ -1348,11 +1412,14 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
         float accS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = bi; k < P.n_block; k += gp)
             bwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds, tiles, accT, accS);
-        WaveList wl = wave_list(J.s, px, gw, lane);
-        for (int k = 0;; ++k) {
-            const int it = wave_list_get(wl, k, lane);
-            if (it < 0) break;
-            bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
+        WaveList wl = wave_list(J.s, px, gw);
+        for (int c0 = 0; c0 < wl.L; c0 += 64) {
+            wave_list_chunk(wl, c0, lane);
+            for (int k = 0;; ++k) {
+                const int it = wave_list_get(wl, k);
+                if (it < 0) break;
+                bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
+            }
         }
         // wavefronts -> workgroup (LDS, wave order), one partial per workgroup in the layout of param_stats1_kernel
         __syncthreads();
@@ -1523,8 +1590,8 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((rc = dev_alloc(g, (size_t)g->N, &g->inv_v, hv.inv.data()))) return rc;
     FusedOrient& A = g->FA;
     FusedOrient& At = g->FAt;
-    A.n_dst = (int)g->M; A.n_src = (int)g->N;
-    At.n_dst = (int)g->N; At.n_src = (int)g->M;
+    A.n_dst = (int)g->M; A.n_src = (int)g->N; A.nnz = (int)g->nnz;
+    At.n_dst = (int)g->N; At.n_src = (int)g->M; At.nnz = (int)g->nnz;
     for (int q = 0; q < NP; ++q) {
         set_tiers(A.t16[q], hc.t16[q]); set_tiers(A.t1[q], hc.t1[q]);
         set_tiers(At.t16[q], hv.t16[q]); set_tiers(At.t1[q], hv.t1[q]);
@@ -1649,6 +1716,7 @@ int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t
         L.n_jobs = 2;
         L.job[0] = fwd_job16(g->FAt, m.cp[2], m.c[2], m.h1c, m.h1v, m.h2v);
         L.job[1] = fwd_job16(g->FA, m.cp[3], m.c[3], m.h1v, m.h1c, m.h2c);
+        L.job[0].perm = g->perm_v; L.job[1].perm = g->perm_c;      // read (unconditional prefetch), used by the head only
         hipLaunchKernelGGL(fused_fwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_fwd16 layer 2"))) return rc;
     }

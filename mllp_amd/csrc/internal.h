@@ -66,7 +66,7 @@ struct FusedTiersDev {
 };
 constexpr int FUSED_NP = 8;     // partitions of the instances (host_graph.h::FUSED_PARTS): one per XCD
 struct FusedOrient {
-    int n_dst = 0, n_src = 0;
+    int n_dst = 0, n_src = 0, nnz = 0;
     int* sptr = nullptr;        // [n_dst + 1]
     int* sent = nullptr;        // [nnz][2] {source id (renumbered), value bits}
     float* sax = nullptr;       // [nnz][2] {a_ij, x_src} of the bound layer-1 inputs (scalar node features are data)

@@ -117,26 +117,37 @@ def cpu_baseline(instances, threads):
     small = sorted(instances, key=lambda i: i.nnz)[:3]
     for i in small:            # warm-up (allocator, thread pool)
         tr.step(i)
+    # whole epochs until about 12 s of CPU work have been timed (the contract asks for a 10-30 s sample)
     t0 = time.perf_counter()
-    for i in instances:
-        tr.step(i)
-    dt = time.perf_counter() - t0
+    n_done = epochs = 0
+    while True:
+        for i in instances:
+            tr.step(i)
+        n_done += len(instances)
+        epochs += 1
+        dt = time.perf_counter() - t0
+        if dt >= 12.0 or epochs >= 64:
+            break
     # the same loop with the per-instance graphs cached (a fairer lower bound than the reference's per-step rebuild,
     # SURVEY.md section 8d); the first pass fills the cache and is not timed
     trc = o1.ReferenceTrainer(sd, lr=1e-3, dtype=torch.float32, rebuild_graph=False)
-    half = instances[::2]                      # bounded: every other instance, ~half the time of the epoch above
-    for i in half:
+    for i in instances:
         trc._cache[i.name] = o1.instance_graph(i, torch.float32)
     t1 = time.perf_counter()
-    for i in half:
-        trc.step(i)
-    dtc = time.perf_counter() - t1
-    return dict(value=len(instances) / dt, unit="instances/s", cores=int(torch.get_num_threads()),
+    n_c = 0
+    while True:
+        for i in instances:
+            trc.step(i)
+        n_c += len(instances)
+        dtc = time.perf_counter() - t1
+        if dtc >= 6.0 or n_c >= 64 * len(instances):
+            break
+    return dict(value=n_done / dt, unit="instances/s", cores=int(torch.get_num_threads()),
                 host_cpus=os.cpu_count(), kind="port", seconds=dt,
-                graph_cached={"value": len(half) / dtc, "unit": "instances/s", "seconds": dtc,
-                              "sample": f"{len(half)} of the {len(instances)} instances (every other one), graphs prebuilt"},
-                sample=f"1 epoch of the same {len(instances)} Netlib instances, one Adam step per instance, "
-                       "graph rebuilt per step (reference experiment.py:123-144), fp32 torch CPU; "
+                graph_cached={"value": n_c / dtc, "unit": "instances/s", "seconds": dtc,
+                              "sample": f"{n_c // len(instances)} epochs of the same instances, graphs prebuilt"},
+                sample=f"{epochs} epochs of the same {len(instances)} Netlib instances ({dt:.1f} s), one Adam step per "
+                       "instance, graph rebuilt per step (reference experiment.py:123-144), fp32 torch CPU; "
                        "PyG itself is not installable here, so this is the oracle's restatement")
 
 

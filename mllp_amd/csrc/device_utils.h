@@ -142,6 +142,12 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += dpp_mov<0x4E>(v);
     return v;
 }
+// max over the 4 lanes of a quad (every lane gets it)
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    return v;
+}
 // value held by lane J of the own quad
 template <int J>
 __device__ __forceinline__ float quad_bcast(float v) {

@@ -48,6 +48,7 @@ static int g_fused_abl = [] {
 #define FUSED_ABL(bit) ((J.abl & (bit)) != 0)
 // per-wavefront cycle sums of the segments of fwd16_row (s_memtime), read back by tools/abl_fused.py
 __device__ unsigned long long g_fused_stamps[8192 * 8];
+__device__ unsigned long long g_fused_stamps1[8192 * 8];     // the same for bwd1_row
 #define FUSED_STAMP(k)                                                                      \
     {                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -207,8 +208,10 @@ struct SlotReq {
 template <int G>
 struct Geo {
     static constexpr int U = 64 / G;              // units per wavefront
-    static constexpr int QG = G == 4 ? 4 : 16;    // units per row in the group tier (always 16 lanes = one DPP row)
-    static constexpr int RG = U / QG;             // rows per wavefront in the group tier
+    static constexpr int QG = 4;                  // units per row in the group tier: 4 quads (16-channel sweeps) or 4 lanes
+                                                  // (1-channel sweeps; with 16 lanes per row an item held only 4 rows and
+                                                  // half of all 1-channel items of the Netlib batch were such items)
+    static constexpr int RG = U / QG;             // rows per wavefront in the group tier: 4 / 16
 };
 template <int G>
 __device__ __forceinline__ int wave_items(const PartTiers& s) {
@@ -328,8 +331,8 @@ __device__ __forceinline__ float shared_sum4(float v, int mode) {
 __device__ __forceinline__ float shared_max4(float v, int mode) {
     return mode == 1 ? quads_max<16>(v) : quads_max<64>(v);
 }
-__device__ __forceinline__ float shared_sum1(float v, int mode) { return mode == 1 ? row16_sum(v) : wave_sum(v); }
-__device__ __forceinline__ float shared_max1(float v, int mode) { return mode == 1 ? row16_max(v) : group_max<64>(v); }
+__device__ __forceinline__ float shared_sum1(float v, int mode) { return mode == 1 ? quad_sum(v) : wave_sum(v); }
+__device__ __forceinline__ float shared_max1(float v, int mode) { return mode == 1 ? quad_max(v) : group_max<64>(v); }
 
 // ====================================================================================================
 // forward, 16 source channels
@@ -716,7 +719,7 @@ struct FwdLaunch1 {
     FwdJob1 job[MAXJOBS];
     int n_jobs;
 };
-struct FwdW1 {
+struct alignas(16) FwdW1 {
     float wv[16], ws[16], bv[16], we[16], bs[16];
     float pq, pq0, pt, pt0;
 };
@@ -724,43 +727,65 @@ struct Soft1 {
     float m, L, u, Z;
 };
 
-__device__ __forceinline__ void fwd1_edges(const ItemsDev& s, const RowSlot& r, float qp, float t, Soft1& st) {
+// Eight entries {a_ij, x_src} of a unit (lane / 16 lanes / wavefront per row), requested together.  The loads are
+// unconditional (clamped index; a slot past the row's end is masked where it is used): the first version fetched four
+// entries per step under `k < n ? load : 0`, one round trip to L2 per step of four nonzeros, and a 16-nonzero row
+// cost four of them in sequence (the 1-channel sweeps do a handful of FMAs per nonzero: they are pure latency).
+struct Ent8 {
+    float2 e0, e1, e2, e3, e4, e5, e6, e7;
+};
+__device__ __forceinline__ void ent8_load(const ItemsDev& s, const RowSlot& r, int k0, Ent8& E) {
+    const int last = max(s.nnz - 1, 0), d = r.stride, b = r.first + k0 * d;
+#ifdef MLLP_EXPERIMENT_NO_ENTRY_LOADS      // one-off timing experiment: what the strided entry loads cost
+    E.e0 = E.e1 = E.e2 = E.e3 = E.e4 = E.e5 = E.e6 = E.e7 = make_float2(0.25f, 0.5f);
+    return;
+#endif
+    E.e0 = s.sax[min(b, last)];         E.e1 = s.sax[min(b + d, last)];
+    E.e2 = s.sax[min(b + 2 * d, last)]; E.e3 = s.sax[min(b + 3 * d, last)];
+    E.e4 = s.sax[min(b + 4 * d, last)]; E.e5 = s.sax[min(b + 5 * d, last)];
+    E.e6 = s.sax[min(b + 6 * d, last)]; E.e7 = s.sax[min(b + 7 * d, last)];
+}
+
+// online softmax over four entries (slots k0 .. k0 + 3 of the unit)
+__device__ __forceinline__ void fwd1_step4(const float2& e0, const float2& e1, const float2& e2, const float2& e3, int k0,
+                                           int n_mine, float qp, float t, Soft1& st) {
+    const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
+    const float d0 = ok0 ? fmaf(qp, e0.y, e0.x * t) : NEG_BIG, d1 = ok1 ? fmaf(qp, e1.y, e1.x * t) : NEG_BIG;
+    const float d2 = ok2 ? fmaf(qp, e2.y, e2.x * t) : NEG_BIG, d3 = ok3 ? fmaf(qp, e3.y, e3.x * t) : NEG_BIG;
+    const float mi = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
+    if (__any(mi > st.m)) {
+        const float mn = fmaxf(st.m, mi);
+        const float sc = exp_acc(st.m - mn);
+        st.L *= sc; st.u *= sc; st.Z *= sc;
+        st.m = mn;
+    }
+    const float p0 = ok0 ? exp_acc(d0 - st.m) : 0.0f, p1 = ok1 ? exp_acc(d1 - st.m) : 0.0f;
+    const float p2 = ok2 ? exp_acc(d2 - st.m) : 0.0f, p3 = ok3 ? exp_acc(d3 - st.m) : 0.0f;
+    st.L += (p0 + p1) + (p2 + p3);
+    st.u = fmaf(p0, e0.x, fmaf(p1, e1.x, fmaf(p2, e2.x, fmaf(p3, e3.x, st.u))));
+    st.Z = fmaf(p0, e0.y, fmaf(p1, e1.y, fmaf(p2, e2.y, fmaf(p3, e3.y, st.Z))));
+}
+// E: slots 0 .. 7, requested by the caller before the row's other loads
+__device__ __forceinline__ void fwd1_edges(const ItemsDev& s, const RowSlot& r, float qp, float t, Soft1& st, Ent8& E) {
     const int n_mine = slot_count(r);
-    const float2 z2 = make_float2(0.0f, 0.0f);
-    float2 n0 = 0 < n_mine ? s.sax[r.first] : z2, n1 = 1 < n_mine ? s.sax[r.first + r.stride] : z2;
-    float2 n2 = 2 < n_mine ? s.sax[r.first + 2 * r.stride] : z2, n3 = 3 < n_mine ? s.sax[r.first + 3 * r.stride] : z2;
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        const float2 e0 = n0, e1 = n1, e2 = n2, e3 = n3;
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
-        const int eb = r.first + (k0 + 4) * r.stride;
-        n0 = k0 + 4 < n_mine ? s.sax[eb] : z2;
-        n1 = k0 + 5 < n_mine ? s.sax[eb + r.stride] : z2;
-        n2 = k0 + 6 < n_mine ? s.sax[eb + 2 * r.stride] : z2;
-        n3 = k0 + 7 < n_mine ? s.sax[eb + 3 * r.stride] : z2;
-        const float d0 = ok0 ? fmaf(qp, e0.y, e0.x * t) : NEG_BIG, d1 = ok1 ? fmaf(qp, e1.y, e1.x * t) : NEG_BIG;
-        const float d2 = ok2 ? fmaf(qp, e2.y, e2.x * t) : NEG_BIG, d3 = ok3 ? fmaf(qp, e3.y, e3.x * t) : NEG_BIG;
-        const float mi = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
-        if (__any(mi > st.m)) {
-            const float mn = fmaxf(st.m, mi);
-            const float sc = exp_acc(st.m - mn);
-            st.L *= sc; st.u *= sc; st.Z *= sc;
-            st.m = mn;
-        }
-        const float p0 = ok0 ? exp_acc(d0 - st.m) : 0.0f, p1 = ok1 ? exp_acc(d1 - st.m) : 0.0f;
-        const float p2 = ok2 ? exp_acc(d2 - st.m) : 0.0f, p3 = ok3 ? exp_acc(d3 - st.m) : 0.0f;
-        st.L += (p0 + p1) + (p2 + p3);
-        st.u = fmaf(p0, e0.x, fmaf(p1, e1.x, fmaf(p2, e2.x, fmaf(p3, e3.x, st.u))));
-        st.Z = fmaf(p0, e0.y, fmaf(p1, e1.y, fmaf(p2, e2.y, fmaf(p3, e3.y, st.Z))));
+    for (int k0 = 0; __any(k0 < n_mine); k0 += 8) {
+        Ent8 N;
+        const bool more = __any(k0 + 8 < n_mine);
+        if (more) ent8_load(s, r, k0 + 8, N);
+        fwd1_step4(E.e0, E.e1, E.e2, E.e3, k0, n_mine, qp, t, st);
+        if (__any(k0 + 4 < n_mine)) fwd1_step4(E.e4, E.e5, E.e6, E.e7, k0 + 4, n_mine, qp, t, st);
+        if (more) E = N;
     }
 }
 
 __device__ __forceinline__ void fwd1_row(const FwdJob1& J, const FwdW1& W, const RowSlot& r, int lane, float* merge_lds) {
-    const bool have = r.row >= 0;
-    const float x = have ? J.x_dst[r.row] : 0.0f;
+    Ent8 E;
+    ent8_load(J.s, r, 0, E);
+    const float x = J.x_dst[max(r.row, 0)];      // row 0 for a lane without a row: never stored
     const float qp = fmaf(W.pq, x, W.pq0), t = fmaf(W.pt, x, W.pt0);
     Soft1 st;
     st.m = NEG_BIG; st.L = 0.0f; st.u = 0.0f; st.Z = 0.0f;
-    fwd1_edges(J.s, r, qp, t, st);
+    fwd1_edges(J.s, r, qp, t, st, E);
     if (r.mode >= 1) {
         const float M = shared_max1(st.m, r.mode);
         const float f = exp_acc(st.m - M);
@@ -786,9 +811,34 @@ __device__ __forceinline__ void fwd1_row(const FwdJob1& J, const FwdW1& W, const
         st.m = M; st.L = L; st.u = u; st.Z = Z;
         __syncthreads();
     }
-    if (!r.writer) return;
     const float rinv = 1.0f / (st.L + 1e-16f);
     const float S = st.L * rinv, un = st.u * rinv, zn = st.Z * rinv;
+    if (r.mode == 0) {
+        // Base tier: the item's 64 output rows are consecutive -> h is stored COALESCED (lane l writes float4 number
+        // l + 64 q of the item's 4 KB: row (l + 64 q) / 4), the row's four scalars fetched from its lane by ds_bpermute.
+        // A lane storing its own 64-byte row made every store instruction touch 64 cache lines.
+        const int base_row = __builtin_amdgcn_readfirstlane(r.row);          // lane 0 of a base item always has a row
+        const int n_valid = __popcll(__ballot(r.row >= 0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, row_l = idx >> 2, ch = (idx & 3) * 4;
+            const float Sr = __shfl(S, row_l, 64), ur = __shfl(un, row_l, 64), zr = __shfl(zn, row_l, 64), xr = __shfl(x, row_l, 64);
+            float4 v = lds4(W.bs + ch);
+            fma4(Sr, lds4(W.bv + ch), v);
+            fma4(ur, lds4(W.we + ch), v);
+            fma4(zr, lds4(W.wv + ch), v);
+            fma4(xr, lds4(W.ws + ch), v);
+            if (row_l < n_valid)
+                *reinterpret_cast<float4*>(J.h + (size_t)(base_row + row_l) * 16 + ch) =
+                    make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+        }
+        if (r.writer) {
+            J.Z[r.row] = zn;
+            reinterpret_cast<float4*>(J.aux)[r.row] = make_float4(un, st.L > 0.0f ? st.m : 0.0f, rinv, S);
+        }
+        return;
+    }
+    if (!r.writer) return;
     float o[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -834,10 +884,15 @@ __global__ __launch_bounds__(FT) void fused_fwd1_kernel(FwdLaunch1 A) {
         WaveList wl = wave_list(J.s, px, gw);
         for (int c0 = 0; c0 < wl.L; c0 += 64) {
             wave_list_chunk(wl, c0, lane);
-            for (int k = 0;; ++k) {
-                const int it = wave_list_get(wl, k);
-                if (it < 0) break;
-                fwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds);
+            // row pointers of item k + 1 requested before item k is worked on
+            int it = wave_list_get(wl, 0);
+            SlotReq q = item_request<1>(J.s, P, max(it, 0), lane);
+            for (int k = 0; it >= 0; ++k) {
+                const int itn = wave_list_get(wl, k + 1);
+                const RowSlot r = slot_make(q);
+                q = item_request<1>(J.s, P, max(itn, 0), lane);
+                fwd1_row(J, Ws_[j], r, lane, merge_lds);
+                it = itn;
             }
         }
     }
@@ -864,6 +919,8 @@ struct BwdJob16 {
     const float* __restrict__ aux;
     float* __restrict__ rec;           // [n_dst, REC_W] or nullptr (no source-major sweep follows)
     float* __restrict__ dx_dst;        // [n_dst, 16] or nullptr
+    int mask_dx;                       // dx_dst is stored times (x_dst > 0): x_dst is a ReLU output and the consumer of
+                                       // dx_dst (the backward of the layer below) would re-read it only to apply this mask
     float* __restrict__ stats;         // [grid, STAT_FLOATS]
 #ifdef MLLP_TIMING_BUILD
     int abl;
@@ -925,6 +982,7 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
                                           int lane, float* merge_lds, float* tiles, f32x4m (&acc)[STAT_TILES]) {
     const bool have = r.row >= 0;
     const bool writer = r.writer;
+    const int xpos = (rd.x.x > 0.0f ? 1 : 0) | (rd.x.y > 0.0f ? 2 : 0) | (rd.x.z > 0.0f ? 4 : 0) | (rd.x.w > 0.0f ? 8 : 0);
     const int n_mine = FUSED_ABL(1) ? 0 : slot_count(r);
     Gather4 gt;
     gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
@@ -1009,6 +1067,12 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         float4 v = tile_get(tiles + TB_SC * TILE, lane);
         fma4(st.ds, lds4(W.Pb + 4 * part), v);
         fma4(st.dt, lds4(W.Pt + 4 * part), v);
+        if (J.mask_dx) {
+            if (!(xpos & 1)) v.x = 0.0f;
+            if (!(xpos & 2)) v.y = 0.0f;
+            if (!(xpos & 4)) v.z = 0.0f;
+            if (!(xpos & 8)) v.w = 0.0f;
+        }
         if (writer) *reinterpret_cast<float4*>(J.dx_dst + (size_t)r.row * 16 + 4 * part) = v;
     }
     // statistics (node_kernels.hip::param_stats16_kernel): operands with m / n = channel, k = row.  A row shared by
@@ -1134,6 +1198,12 @@ struct SrcJob16 {
     const float* __restrict__ x;       // [n_rows, 16] features of the rows
     const float* __restrict__ rec;     // [n_cols, REC_W]
     float* __restrict__ dx;            // [n_rows, 16]
+    // the rows' features are ReLU outputs and dx is the gradient with respect to them: stored as
+    // (x > 0) * (dx + addw * addp[row]) -- the layer below then reads ONE pre-masked gradient per node instead of two
+    // gradient parts and the activations (addp is always readable: x itself with addw = 0 when there is nothing to add)
+    const float* __restrict__ addp;
+    float addw;
+    int mask;
 };
 struct SrcLaunch16 {
     SrcJob16 job[MAXJOBS];
@@ -1169,6 +1239,7 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, f
                                           RowSlot& rn, int part, int lane, float* merge_lds) {
     const int n_mine = slot_count(r);
     const float4 xj = xj_io;
+    const float4 addv = ld4(J.addp + (size_t)max(r.row, 0) * 16 + 4 * part);     // lands during the sweep
     float4 acc = f4zero();
     for (int k0 = 0; __any(k0 < n_mine); k0 += 2) {
         const int colm = en.x;
@@ -1219,6 +1290,13 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, f
         acc = v;
         __syncthreads();
     }
+    fma4(J.addw, addv, acc);
+    if (J.mask) {
+        if (!(xj.x > 0.0f)) acc.x = 0.0f;
+        if (!(xj.y > 0.0f)) acc.y = 0.0f;
+        if (!(xj.z > 0.0f)) acc.z = 0.0f;
+        if (!(xj.w > 0.0f)) acc.w = 0.0f;
+    }
     if (r.writer) *reinterpret_cast<float4*>(J.dx + (size_t)r.row * 16 + 4 * part) = acc;
 }
 
@@ -1267,9 +1345,7 @@ struct BwdJob1 {
     const float* __restrict__ x_dst;   // [n_dst] renumbered
     const float* __restrict__ D;
     ConvParams p;
-    const float* __restrict__ h;       // [n_dst, 16]
-    const float* __restrict__ dh_a;    // [n_dst, 16]
-    const float* __restrict__ dh_b;    // [n_dst, 16] or nullptr
+    const float* __restrict__ g;       // [n_dst, 16] gradient of the conv's output, ReLU mask applied by its producer
     const float* __restrict__ Z;       // [n_dst]
     const float* __restrict__ aux;     // [n_dst, 4]
     float* __restrict__ stats;         // [grid, STAT_FLOATS]
@@ -1278,7 +1354,7 @@ struct BwdLaunch1 {
     BwdJob1 job[MAXJOBS];
     int n_jobs;
 };
-struct BwdW1 {
+struct alignas(16) BwdW1 {
     float wv[16], bv[16], we[16];
     float pq, pq0, pt, pt0;
 };
@@ -1286,23 +1362,49 @@ constexpr int G1S = 17, R1S = 9;                       // row strides of the g t
 constexpr int TILE1 = 64 * G1S + 64 * R1S;             // floats per wavefront
 
 __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const RowSlot& r, int lane, float* merge_lds,
-                                         float* tiles, f32x4m& accT, float (&accS)[6]) {
-    const bool have = r.row >= 0;
+                                         float* tiles, f32x4m& accT, float (&accS)[6]
+#ifdef MLLP_TIMING_BUILD
+                                         , unsigned long long (&stamp_sum)[8], unsigned long long& stamp_last
+#endif
+) {
+    FUSED_STAMP(0)      // between items
     const bool writer = r.writer;
+    Ent8 E;
+    ent8_load(J.s, r, 0, E);           // the first eight entries leave before the row's own data
+    const int rowc = max(r.row, 0);    // row 0 for a lane without a row: nothing of it is counted (writer is false)
     float gv = 0.0f, ge = 0.0f, gb = 0.0f;
-    {   // g = (dh_a + dh_b) * (h > 0); the row of g goes to the tile (zeros unless this lane owns the row)
-        const size_t ro = (size_t)(have ? r.row : 0) * 16;
-        const float4* pa = reinterpret_cast<const float4*>(J.dh_a + ro);
-        const float4* pb = reinterpret_cast<const float4*>((J.dh_b ? J.dh_b : J.dh_a) + ro);
-        const float4* ph = reinterpret_cast<const float4*>(J.h + ro);
+    if (r.mode == 0) {
+        // Base tier (a lane per row, the item's 64 rows are consecutive): dh_a / dh_b / h are read COALESCED, lane l
+        // taking float4 number l + 64 q of the item's 4 KB (row (l + 64 q) / 4, channels 4 ((l + 64 q) & 3) ...), the
+        // three dot products reduced over the quad and handed to the row's own lane through the free columns of the
+        // R tile.  One lane reading its own 64-byte row made every load instruction touch 64 cache lines: 11.4 k of
+        // the 18.5 k cycles of an item went into this block (in-kernel stamps), the vector-memory path being shared by
+        // the CU's 12 wavefronts.
+        const int base_row = __builtin_amdgcn_readfirstlane(r.row);          // lane 0 of a base item always has a row
+        const int n_valid = __popcll(__ballot(r.row >= 0));
+        float* gt = tiles;
+        float* rt = tiles + 64 * G1S;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q, row_l = idx >> 2, ch = (idx & 3) * 4;
+            const size_t ro = (size_t)min(base_row + row_l, J.s.n_dst - 1) * 16 + ch;
+            const float4 a = ld4(J.g + ro);
+            const bool on = row_l < n_valid;
+            const float4 g = make_float4(on ? a.x : 0.0f, on ? a.y : 0.0f, on ? a.z : 0.0f, on ? a.w : 0.0f);
+            const float pv = quad_sum(dot4(g, lds4(W.wv + ch))), pe = quad_sum(dot4(g, lds4(W.we + ch)));
+            const float pb = quad_sum(dot4(g, lds4(W.bv + ch)));
+            float* d = gt + row_l * G1S + ch;
+            d[0] = g.x; d[1] = g.y; d[2] = g.z; d[3] = g.w;
+            if ((lane & 3) == 0) { rt[row_l * R1S + 5] = pv; rt[row_l * R1S + 6] = pe; rt[row_l * R1S + 7] = pb; }
+        }
+        gv = rt[lane * R1S + 5]; ge = rt[lane * R1S + 6]; gb = rt[lane * R1S + 7];      // same wavefront: LDS in order
+    } else {   // the row of g goes to the tile (zeros unless this lane owns the row)
+        const float4* pa = reinterpret_cast<const float4*>(J.g + (size_t)rowc * 16);
         float* gt = tiles + lane * G1S;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 a = have ? pa[q] : f4zero();
-            if (J.dh_b && have) a = f4add(a, pb[q]);
-            const float4 hv = have ? ph[q] : f4zero();
-            const float g0 = hv.x > 0.0f ? a.x : 0.0f, g1 = hv.y > 0.0f ? a.y : 0.0f;
-            const float g2 = hv.z > 0.0f ? a.z : 0.0f, g3 = hv.w > 0.0f ? a.w : 0.0f;
+            const float4 a = pa[q];
+            const float g0 = a.x, g1 = a.y, g2 = a.z, g3 = a.w;
             gv = fmaf(g0, W.wv[4 * q], fmaf(g1, W.wv[4 * q + 1], fmaf(g2, W.wv[4 * q + 2], fmaf(g3, W.wv[4 * q + 3], gv))));
             ge = fmaf(g0, W.we[4 * q], fmaf(g1, W.we[4 * q + 1], fmaf(g2, W.we[4 * q + 2], fmaf(g3, W.we[4 * q + 3], ge))));
             gb = fmaf(g0, W.bv[4 * q], fmaf(g1, W.bv[4 * q + 1], fmaf(g2, W.bv[4 * q + 2], fmaf(g3, W.bv[4 * q + 3], gb))));
@@ -1312,9 +1414,9 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
             gt[4 * q + 3] = writer ? g3 : 0.0f;
         }
     }
-    const float x = have ? J.x_dst[r.row] : 0.0f;
-    const float Zn = have ? J.Z[r.row] : 0.0f;
-    const float4 ax = have ? reinterpret_cast<const float4*>(J.aux)[r.row] : f4zero();   // {u, rowmax, rinv, S}
+    const float x = J.x_dst[rowc];
+    const float Zn = J.Z[rowc];
+    const float4 ax = reinterpret_cast<const float4*>(J.aux)[rowc];   // {u, rowmax, rinv, S}
     {
         float* rt = tiles + 64 * G1S + lane * R1S;
         rt[0] = writer ? x : 0.0f;
@@ -1328,32 +1430,34 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
     const float qp = fmaf(W.pq, x, W.pq0), t = fmaf(W.pt, x, W.pt0);
     float ds = 0.0f, dt = 0.0f, dq = 0.0f;
     const int n_mine = slot_count(r);
-    const float2 z2 = make_float2(0.0f, 0.0f);
-    float2 n0 = 0 < n_mine ? J.s.sax[r.first] : z2, n1 = 1 < n_mine ? J.s.sax[r.first + r.stride] : z2;
-    float2 n2 = 2 < n_mine ? J.s.sax[r.first + 2 * r.stride] : z2, n3 = 3 < n_mine ? J.s.sax[r.first + 3 * r.stride] : z2;
-    for (int k0 = 0; __any(k0 < n_mine); k0 += 4) {
-        const float2 e0 = n0, e1 = n1, e2 = n2, e3 = n3;
-        const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine, ok2 = k0 + 2 < n_mine, ok3 = k0 + 3 < n_mine;
-        const int eb = r.first + (k0 + 4) * r.stride;
-        n0 = k0 + 4 < n_mine ? J.s.sax[eb] : z2;
-        n1 = k0 + 5 < n_mine ? J.s.sax[eb + r.stride] : z2;
-        n2 = k0 + 6 < n_mine ? J.s.sax[eb + 2 * r.stride] : z2;
-        n3 = k0 + 7 < n_mine ? J.s.sax[eb + 3 * r.stride] : z2;
-#define MLLP_BWD1_SLOT(OK, E_)                                                             \
+    FUSED_STAMP(1)      // row data, g tile
+    for (int k0 = 0; __any(k0 < n_mine); k0 += 8) {
+        Ent8 N;
+        const bool more = __any(k0 + 8 < n_mine);
+        if (more) ent8_load(J.s, r, k0 + 8, N);
+#define MLLP_BWD1_SLOT(K, E_)                                                              \
     {                                                                                      \
         const float l_ = fmaf(qp, E_.y, E_.x * t);                                         \
-        const float al_ = OK ? exp_acc(l_ - ax.y) * ax.z : 0.0f;                           \
+        const float al_ = (K) < n_mine ? exp_acc(l_ - ax.y) * ax.z : 0.0f;                 \
         const float dl_ = al_ * fmaf(gv, E_.y, fmaf(E_.x, ge, cc));                        \
         ds += dl_;                                                                         \
         dt = fmaf(dl_, E_.x, dt);                                                          \
         dq = fmaf(dl_, E_.y, dq);                                                          \
     }
-        MLLP_BWD1_SLOT(ok0, e0)
-        MLLP_BWD1_SLOT(ok1, e1)
-        MLLP_BWD1_SLOT(ok2, e2)
-        MLLP_BWD1_SLOT(ok3, e3)
+        MLLP_BWD1_SLOT(k0, E.e0)
+        MLLP_BWD1_SLOT(k0 + 1, E.e1)
+        MLLP_BWD1_SLOT(k0 + 2, E.e2)
+        MLLP_BWD1_SLOT(k0 + 3, E.e3)
+        if (__any(k0 + 4 < n_mine)) {
+            MLLP_BWD1_SLOT(k0 + 4, E.e4)
+            MLLP_BWD1_SLOT(k0 + 5, E.e5)
+            MLLP_BWD1_SLOT(k0 + 6, E.e6)
+            MLLP_BWD1_SLOT(k0 + 7, E.e7)
+        }
 #undef MLLP_BWD1_SLOT
+        if (more) E = N;
     }
+    FUSED_STAMP(2)      // sweep
     if (r.mode >= 1) {
         ds = shared_sum1(ds, r.mode); dt = shared_sum1(dt, r.mode); dq = shared_sum1(dq, r.mode);
     }
@@ -1378,6 +1482,7 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
         accS[4] += ds;                      // T6[0][0]
         accS[5] += dt;                      // T6[1][0]
     }
+    FUSED_STAMP(3)      // merges, scalar sums
     // T[o][n] += sum over the 64 rows of the wavefront: 16 MFMA steps of 4 rows
     const float* gt = tiles;
     const float* rt = tiles + 64 * G1S;
@@ -1388,6 +1493,7 @@ __device__ __forceinline__ void bwd1_row(const BwdJob1& J, const BwdW1& W, const
         const float b = rr < 5 ? rt[(4 * s + kq) * R1S + rr] : 0.0f;
         accT = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accT, 0, 0, 0);
     }
+    FUSED_STAMP(4)      // statistics on the MFMA
 }
 
 __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
@@ -1405,20 +1511,35 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
     float* tiles = tiles_ + wave * TILE1;
     const int px = blockIdx.x % NP, bi = blockIdx.x / NP, gp = gridDim.x / NP;
     const int gw = bi * FW + wave;
+#ifdef MLLP_TIMING_BUILD
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_begin = stamp_last;
+#define STAMP_ARGS1 , stamp_sum, stamp_last
+#else
+#define STAMP_ARGS1
+#endif
     for (int j = 0; j < A.n_jobs; ++j) {
         const BwdJob1& J = A.job[j];
         const PartTiers P = J.s.part[px];
         f32x4m accT = splat4(0.0f);
         float accS[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = bi; k < P.n_block; k += gp)
-            bwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds, tiles, accT, accS);
+            bwd1_row(J, Ws_[j], block_slot<1>(J.s, P.row0 + k, tid), lane, merge_lds, tiles, accT, accS STAMP_ARGS1);
         WaveList wl = wave_list(J.s, px, gw);
         for (int c0 = 0; c0 < wl.L; c0 += 64) {
             wave_list_chunk(wl, c0, lane);
-            for (int k = 0;; ++k) {
-                const int it = wave_list_get(wl, k);
-                if (it < 0) break;
-                bwd1_row(J, Ws_[j], item_slot<1>(J.s, P, it, lane), lane, merge_lds, tiles, accT, accS);
+            int it = wave_list_get(wl, 0);
+            SlotReq q = item_request<1>(J.s, P, max(it, 0), lane);
+            for (int k = 0; it >= 0; ++k) {
+                const int itn = wave_list_get(wl, k + 1);
+                const RowSlot r = slot_make(q);
+                q = item_request<1>(J.s, P, max(itn, 0), lane);
+                bwd1_row(J, Ws_[j], r, lane, merge_lds, tiles, accT, accS STAMP_ARGS1);
+#ifdef MLLP_TIMING_BUILD
+                stamp_sum[7] += 1;
+#endif
+                it = itn;
             }
         }
         // wavefronts -> workgroup (LDS, wave order), one partial per workgroup in the layout of param_stats1_kernel
@@ -1448,7 +1569,18 @@ __global__ __launch_bounds__(FT) void fused_bwd1_kernel(BwdLaunch1 A) {
             else if (n < 5) dst[512 + o * 16 + (n - 2)] = v;    // T2[o][0..2] = sum g_o {1, S, u}
         }
         __syncthreads();
+#ifdef MLLP_TIMING_BUILD
+        stamp_last = __builtin_amdgcn_s_memtime();      // the job's reduction is not part of "between items"
+#endif
     }
+#ifdef MLLP_TIMING_BUILD
+    if (lane == 0) {
+        stamp_sum[6] = __builtin_amdgcn_s_memtime() - stamp_begin;
+        unsigned long long* d = g_fused_stamps1 + (size_t)(blockIdx.x * FW + wave) * 8;
+        for (int k = 0; k < 8; ++k) d[k] = stamp_sum[k];
+    }
+#endif
+#undef STAMP_ARGS1
 }
 
 // ====================================================================================================
@@ -1551,6 +1683,9 @@ __global__ void fused_pregather_kernel(int64_t nnz, const int2* __restrict__ sen
 #ifdef MLLP_TIMING_BUILD
 extern "C" int mllp_timing_read_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fused_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mllp_timing_read_stamps1(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fused_stamps1), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1743,40 +1878,44 @@ int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* d
 }
 
 static BwdJob16 bwd_job16(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_src, const float* x_dst,
-                          const float* h, const float* dh_a, const float* dh_b, float* dx_dst, bool need_rec) {
+                          const float* h, const float* dh_a, const float* dh_b, float* dx_dst, bool need_rec, bool mask_dx) {
     BwdJob16 J = {};
     J.s = items_dev(o, 0);
     J.x_src = x_src; J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 16);
     J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux;
     J.rec = need_rec ? w.rec : nullptr;
     J.dx_dst = dx_dst;
+    J.mask_dx = mask_dx ? 1 : 0;
     J.stats = w.stats;
 #ifdef MLLP_TIMING_BUILD
     J.abl = g_fused_abl;
 #endif
     return J;
 }
-static SrcJob16 src_job16(const FusedOrient& o_src_major, const ConvWs& w, const float* x_rows, float* dx) {
+static SrcJob16 src_job16(const FusedOrient& o_src_major, const ConvWs& w, const float* x_rows, float* dx, const float* add) {
     SrcJob16 J = {};
     J.s = items_dev(o_src_major, 2);
     J.x = x_rows; J.rec = w.rec; J.dx = dx;
+    J.addp = add ? add : x_rows; J.addw = add ? 1.0f : 0.0f; J.mask = 1;
     return J;
 }
-static BwdJob1 bwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, const float* h,
-                        const float* dh_a, const float* dh_b) {
+static BwdJob1 bwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, const float* x_dst, const float* g_masked) {
     BwdJob1 J = {};
     J.s = items_dev(o, 1);
     J.x_dst = x_dst; J.D = w.derived; J.p = conv_params_at(cp, 1);
-    J.h = h; J.dh_a = dh_a; J.dh_b = dh_b; J.Z = w.Z; J.aux = w.aux; J.stats = w.stats;
+    J.g = g_masked; J.Z = w.Z; J.aux = w.aux; J.stats = w.stats;
     return J;
 }
 
-// Backward chain (linear_program_methods.py:241-247 read backwards), one stream:
-//   K1  C3  dst  (dh = d3v [premasked when it came from the fused head]) -> rec3, d2v
-//   K2  C3  src  -> d2c                      K2' C2V dst (dh = d2v) -> rec2v, d1v
-//   K3  C2C dst  (dh = d2c) -> rec2c, d1c    K3' C2V src -> d1c_b
-//   K4  C2C src  -> d1v_b
-//   K5  C1C dst (dh = d1c + d1c_b) and C1V dst (dh = d1v + d1v_b) in one launch
+// Backward chain (linear_program_methods.py:241-247 read backwards), one stream.  Every gradient of a hidden activation is
+// stored already multiplied by the ReLU mask of that activation by the kernel that produces it (it has the activation
+// in registers as its own x), and the two parts of the layer-1 gradients are summed by the second producer: the
+// consumers read one array per node and no activations for masking.
+//   K1  C3  dst  (dh = d3v [premasked when it came from the fused head]) -> rec3, d2v (masked by h2v)
+//   K2  C3  src  -> d2c (masked by h2c)                 K2' C2V dst (dh = d2v) -> rec2v, d1v (masked by h1v)
+//   K3  C2C dst  (dh = d2c) -> rec2c, d1c (masked)      K3' C2V src -> d1c_b = (h1c > 0) (dX + d1c)
+//   K4  C2C src  -> d1v_b = (h1v > 0) (dX + d1v)
+//   K5  C1C dst (g = d1c_b) and C1V dst (g = d1v_b) in one launch
 //   K6  reduce the statistics partials (+ fc partials), K7 finalize (node_kernels.hip)
 int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s) {
     const int G = fused_grid(g);
@@ -1786,40 +1925,40 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
     {   // K1
         BwdLaunch16 L = {};
         L.n_jobs = 1;
-        L.job[0] = bwd_job16(At, m.cp[4], m.c[4], m.h2c, m.h2v, premasked ? nullptr : m.h3v, m.d3v, nullptr, m.d2v, true);
+        L.job[0] = bwd_job16(At, m.cp[4], m.c[4], m.h2c, m.h2v, premasked ? nullptr : m.h3v, m.d3v, nullptr, m.d2v, true, true);
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C3"))) return rc;
     }
     {   // K2: C3 source-major (rows = constraints) and C2V destination-major
         SrcLaunch16 S = {};
         S.n_jobs = 1;
-        S.job[0] = src_job16(A, m.c[4], m.h2c, m.d2c);
+        S.job[0] = src_job16(A, m.c[4], m.h2c, m.d2c, nullptr);
         hipLaunchKernelGGL(fused_src16_kernel, dim3(2 * G), dim3(FT), 0, s, S);   // 72 VGPRs: two workgroups per CU
         if ((rc = check_launch("fused_src16 C3"))) return rc;
         BwdLaunch16 L = {};
         L.n_jobs = 1;
-        L.job[0] = bwd_job16(At, m.cp[2], m.c[2], m.h1c, m.h1v, m.h2v, m.d2v, nullptr, m.d1v, true);
+        L.job[0] = bwd_job16(At, m.cp[2], m.c[2], m.h1c, m.h1v, nullptr, m.d2v, nullptr, m.d1v, true, true);
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C2V"))) return rc;
     }
     {   // K3: C2C destination-major (rows = constraints) and C2V source-major (rows = constraints)
         BwdLaunch16 L = {};
         L.n_jobs = 1;
-        L.job[0] = bwd_job16(A, m.cp[3], m.c[3], m.h1v, m.h1c, m.h2c, m.d2c, nullptr, m.d1c, true);
+        L.job[0] = bwd_job16(A, m.cp[3], m.c[3], m.h1v, m.h1c, nullptr, m.d2c, nullptr, m.d1c, true, true);
         hipLaunchKernelGGL(fused_bwd16_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd16 C2C"))) return rc;
         SrcLaunch16 S = {};
         S.n_jobs = 2;
-        S.job[0] = src_job16(A, m.c[2], m.h1c, m.d1c_b);
-        S.job[1] = src_job16(At, m.c[3], m.h1v, m.d1v_b);      // K4: C2C source-major (rows = variables)
+        S.job[0] = src_job16(A, m.c[2], m.h1c, m.d1c_b, m.d1c);      // d1c_b = (h1c > 0) (dX + d1c): the whole gradient of h1c
+        S.job[1] = src_job16(At, m.c[3], m.h1v, m.d1v_b, m.d1v);     // K4: C2C source-major (rows = variables)
         hipLaunchKernelGGL(fused_src16_kernel, dim3(2 * G), dim3(FT), 0, s, S);   // 72 VGPRs: two workgroups per CU
         if ((rc = check_launch("fused_src16 C2V + C2C"))) return rc;
     }
     {   // K5: layer 1, both convs (inputs are data: no input gradients)
         BwdLaunch1 L = {};
         L.n_jobs = 2;
-        L.job[0] = bwd_job1(A, m.cp[1], m.c[1], g->x2_p, m.h1c, m.d1c, m.d1c_b);
-        L.job[1] = bwd_job1(At, m.cp[0], m.c[0], g->x1_p, m.h1v, m.d1v, m.d1v_b);
+        L.job[0] = bwd_job1(A, m.cp[1], m.c[1], g->x2_p, m.d1c_b);     // pre-masked, pre-summed by K3' / K4
+        L.job[1] = bwd_job1(At, m.cp[0], m.c[0], g->x1_p, m.d1v_b);
         hipLaunchKernelGGL(fused_bwd1_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd1"))) return rc;
     }

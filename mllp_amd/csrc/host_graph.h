@@ -72,7 +72,7 @@ struct HostFusedOrient {
 // wavefronts of its workgroup ~25 k cycles each (LDS merges, barriers).  (Measured: block tier above 2048 -> the
 // wavefront that drew the longest row ran 116 k cycles and set the launch; above 256 -> 247 block rows.)
 constexpr int FUSED_T16[3] = {16, 64, 1024};
-constexpr int FUSED_T1[3] = {16, 128, 4096};     // lane / group (16 lanes) / wave (64 lanes) / block
+constexpr int FUSED_T1[3] = {16, 64, 4096};      // lane / group (4 lanes, 16 rows per item) / wave (64 lanes) / block
 // Cost model of the sweeps, in cycles of one wavefront (stamps of fused_fwd16_kernel on the Netlib batch)
 constexpr int64_t FUSED_COST_ITEM = 5300, FUSED_COST_STEP = 2000, FUSED_COST_BLOCK_ROW = 25000;
 // Estimated cycles of one 16-channel sweep over every instance's rows of one orientation (ptr: row pointers, inst_off:
@@ -94,7 +94,7 @@ void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& 
 // a wavefront accumulates are summed in a fixed order): wavefronts are charged the block rows of their workgroup first
 // (row k of a partition goes to workgroup k mod gp), then every item, heaviest first, goes to the least loaded
 // wavefront of its partition.  order[(q * waves_per_part + w) * L + k] = k-th item of wavefront w of partition q, -1 =
-// none.  `scalar`: the 1-channel geometry (64 base rows / 4 group rows per item) instead of 16 / 4.
+// none.  `scalar`: the 1-channel geometry (64 base rows / 16 group rows per item) instead of 16 / 4.
 struct HostWaveLists {
     std::vector<int> order;
     int L = 0, waves_per_part = 0;

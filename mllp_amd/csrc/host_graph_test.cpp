@@ -175,7 +175,8 @@ static void check_fused(const int* ptr, int n, const std::vector<int64_t>& off, 
             CHECK(a.max_load * (int64_t)FUSED_PARTS * nw >= a.sum_load);
             for (int q = 0; q < FUSED_PARTS; ++q) {
                 const FusedTiers& t = scalar ? o.t1[q] : o.t16[q];
-                const int n_items = t.n_wave + (t.n_group + 3) / 4 + (t.n_base + (scalar ? 63 : 15)) / (scalar ? 64 : 16);
+                const int n_items = t.n_wave + (t.n_group + (scalar ? 15 : 3)) / (scalar ? 16 : 4) +
+                                    (t.n_base + (scalar ? 63 : 15)) / (scalar ? 64 : 16);
                 std::vector<int> seen(n_items, 0);
                 size_t longest = 0;
                 for (int w = 0; w < nw; ++w) {

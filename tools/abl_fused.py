@@ -54,3 +54,18 @@ for px in range(8):
 it = a[:, 7].reshape(-1, 12)
 print("items per wavefront, partition 0, first 6 WGs:", it[0:48:8].astype(int).tolist())
 print("cycles per wavefront, partition 0, first 6 WGs (k):", (w[0:48:8] / 1e3).round(0).astype(int).tolist())
+
+# bwd1 (layer-1 backward, both jobs) of the last loss_step
+b.loss_step(params, None, logits, loss, grads)
+torch.cuda.synchronize()
+assert ctypes.CDLL(_lib.LIB_PATH).mllp_timing_read_stamps1(buf, 3072 * 8) == 0
+a = np.array(buf, dtype=np.float64).reshape(3072, 8)
+items = a[:, 7].sum()
+names = ["between items", "row data, g tile", "sweep", "merges, scalar sums", "statistics on the MFMA"]
+print(f"bwd1 (both jobs): {int(items)} items, {a[:, 6].mean():.0f} cycles per wavefront, {a[:, 6].max():.0f} max; per item:")
+for k, nm in enumerate(names):
+    print(f"   {nm:34s} {a[:, k].sum() / items:8.0f} cycles")
+print(f"   {'sum':34s} {a[:, :5].sum() / items:8.0f} cycles;  items per wavefront mean {a[:,7].mean():.2f} max {a[:,7].max():.0f}")
+w = a[:, 6].reshape(-1, 12)
+for px in range(8):
+    print(f"  part {px}: max-wave per WG (k):", " ".join(f"{v:4.0f}" for v in (w[px::8].max(1) / 1e3)[:32]))

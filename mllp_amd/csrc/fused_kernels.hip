@@ -1738,9 +1738,9 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
         FusedOrient* dv[2] = {&A, &At};
         for (int k = 0; k < 2; ++k) {
             HostWaveLists l16, l16x2, l1;
-            host_build_wave_lists(*ho[k], false, gp * FW, FW, &l16);
-            host_build_wave_lists(*ho[k], false, 2 * gp * FW, FW, &l16x2);
-            host_build_wave_lists(*ho[k], true, gp * FW, FW, &l1);
+            host_build_wave_lists(*ho[k], false, gp * FW, FW, 4, &l16);
+            host_build_wave_lists(*ho[k], false, 2 * gp * FW, FW, 2, &l16x2);      // fused_src16_kernel: 2 nonzeros per step
+            host_build_wave_lists(*ho[k], true, gp * FW, FW, 8, &l1);
             FusedOrient& d = *dv[k];
             d.L16 = l16.L; d.nw16 = l16.waves_per_part;
             d.L16x2 = l16x2.L; d.nw16x2 = l16x2.waves_per_part;

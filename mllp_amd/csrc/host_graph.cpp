@@ -213,14 +213,15 @@ void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& 
     for (int q = 0; q < FUSED_PARTS; ++q) o.row0[q + 1] += o.row0[q];
 }
 
-void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, HostWaveLists* out) {
+void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, int nnz_per_step,
+                           HostWaveLists* out) {
     HostWaveLists& wl = *out;
     wl = HostWaveLists();
     const int nw = std::max(waves_per_part, 1), wpg = std::max(std::min(waves_per_wg, nw), 1), gp = std::max(nw / wpg, 1);
     wl.waves_per_part = nw;
     const int U = scalar ? 64 : 16, RG = U / 4;              // base rows / group rows per item (fused_kernels.hip::Geo)
-    // nonzeros of a row per round trip: 4 per quad and step (16 channels); 8 per lane and request (1 channel)
-    const int e_base = scalar ? 8 : 4, e_group = 4 * e_base, e_wave = (scalar ? 64 : 16) * e_base;
+    // nonzeros of a row per round trip: per unit (quad / lane), 4 units per group row, all units of the wavefront
+    const int e_base = std::max(nnz_per_step, 1), e_group = 4 * e_base, e_wave = (scalar ? 64 : 16) * e_base;
     std::vector<std::vector<int>> lists((size_t)FUSED_PARTS * nw);
     for (int q = 0; q < FUSED_PARTS; ++q) {
         const FusedTiers& t = scalar ? o.t1[q] : o.t16[q];

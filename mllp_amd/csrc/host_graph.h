@@ -100,6 +100,9 @@ struct HostWaveLists {
     int L = 0, waves_per_part = 0;
     int64_t max_load = 0, sum_load = 0;     // of the model, over all wavefronts (informational; tests)
 };
-void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, HostWaveLists* out);
+// `nnz_per_step`: nonzeros of a base-tier row that one round trip of the sweep covers (4: forward / destination-major
+// backward, 2: source-major backward, 8: the 1-channel sweeps)
+void host_build_wave_lists(const HostFusedOrient& o, bool scalar, int waves_per_part, int waves_per_wg, int nnz_per_step,
+                           HostWaveLists* out);
 
 }  // namespace mllp

@@ -168,8 +168,8 @@ static void check_fused(const int* ptr, int n, const std::vector<int64_t>& off, 
     for (int scalar = 0; scalar < 2; ++scalar)
         for (int nw : {1, 12, 36, 384}) {
             HostWaveLists a, b;
-            host_build_wave_lists(o, scalar != 0, nw, 12, &a);
-            host_build_wave_lists(o, scalar != 0, nw, 12, &b);
+            host_build_wave_lists(o, scalar != 0, nw, 12, scalar ? 8 : (nw & 1 ? 2 : 4), &a);
+            host_build_wave_lists(o, scalar != 0, nw, 12, scalar ? 8 : (nw & 1 ? 2 : 4), &b);
             CHECK(a.order == b.order && a.L == b.L && a.L >= 1 && a.waves_per_part == nw);
             CHECK(a.order.size() == (size_t)FUSED_PARTS * nw * a.L);
             CHECK(a.max_load * (int64_t)FUSED_PARTS * nw >= a.sum_load);

@@ -267,10 +267,21 @@ def main():
         ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps, warm=5) if tiled_at else ms_gat
         tiled_err = float((Ym - ref_a).abs().max() / ref_a.abs().max())
         gbs_a, gbs_at = b_a / ms_a / 1e6, b_at / ms_at / 1e6
+        # opt-in bf16 feature image of the same kernel (NOT the parity path; printed beside the fp32 line, never as it)
+        bf16_line = None
+        if tiled_a:
+            Hb = Hn.to(torch.bfloat16).contiguous()
+            ms_b = timed(lambda: sb.spmm_bf16(Hb, out=Ym), args.spmm_reps, warm=5)
+            b_b = b_a - sb.N * 32                                   # source rows are 32 bytes instead of 64
+            bf16_line = {"kernel": "spmm_tiled A*H, bf16 feature image (opt-in, fp32 accumulate)", "ms": ms_b,
+                         "alg_bytes": b_b, "GBps": b_b / ms_b / 1e6, "frac": b_b / ms_b / 1e6 / HBM_PEAK_GBS,
+                         "max_rel_diff_vs_fp32": float((Ym - ref_a).abs().max() / ref_a.abs().max())}
+            del Hb
         kernels = [
             {"kernel": "spmm_tiled A*H", "ms": ms_a, "alg_bytes": b_a, "GBps": gbs_a, "frac": gbs_a / HBM_PEAK_GBS,
              "max_rel_diff_vs_generic": tiled_err},
             {"kernel": "spmm_tiled At*H", "ms": ms_at, "alg_bytes": b_at, "GBps": gbs_at, "frac": gbs_at / HBM_PEAK_GBS},
+        ] + ([bf16_line] if bf16_line else []) + [
             {"kernel": "sweep_kernel<SpmmOp> A*H (generic, L2 gathers)", "ms": ms_ga, "alg_bytes": b_a,
              "GBps": b_a / ms_ga / 1e6, "frac": b_a / ms_ga / 1e6 / HBM_PEAK_GBS},
             {"kernel": "sweep_kernel<SpmmOp> At*H (generic, L2 gathers)", "ms": ms_gat, "alg_bytes": b_at,

@@ -103,6 +103,12 @@ int mllp_graph_set_path(mllp_graph_t* g, int path);
  * (gather source rows by edge, scale by a_ij, add into the destination row).
  * ---------------------------------------------------------------------------------------------- */
 int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, float* d_Y, void* stream);
+/* Opt-in bf16 feature image (SURVEY.md 8b `mllp_spmm_csr_f32/_bf16`, BASELINE.json configs[2] "bf16"): the same
+ * product with H given as bf16 [n_src,16] (32-byte rows: half the H traffic and half the LDS image), fp32
+ * values, fp32 accumulation, fp32 Y.  NOT the parity path: the result is the fp32 product of A with H rounded
+ * to bf16 (relative error of an element of H up to 2^-8; the accumulation itself is exact-fp32 as above).
+ * Runs on the LDS-tiled copy only (mllp_graph_attach_tiled, variant 0); MLLP_EINVAL without it.            */
+int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf16, float* d_Y, void* stream);
 
 /* Optional LDS-tiled copy of one orientation for large batches (rows of ~100+ nonzeros): the nonzeros
  * re-blocked into row tiles x column blocks so that source rows are read from LDS instead of L2.

@@ -268,6 +268,18 @@ extern "C" int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const flo
     return launch_spmm(o, d_H, d_Y, o.scratch, (hipStream_t)stream);
 }
 
+extern "C" int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf16, float* d_Y, void* stream) {
+    REQUIRE(g && d_H_bf16 && d_Y, "null argument");
+    const Orient& o = transpose ? g->At : g->A;
+    REQUIRE(o.tiled.n_tiles > 0 || o.n_dst == 0 || g->nnz == 0,
+            "mllp_spmm_csr_bf16 runs on the LDS-tiled copy of the orientation (mllp_graph_attach_tiled, variant 0): attach it first");
+    if (o.tiled.n_tiles == 0) {     // no nonzeros: Y = 0
+        if (o.n_dst > 0) MLLP_HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)o.n_dst * 16 * sizeof(float), (hipStream_t)stream));
+        return MLLP_OK;
+    }
+    return launch_spmm_tiled_bf16(o.tiled, o.n_dst, o.n_src, d_H_bf16, d_Y, (hipStream_t)stream);
+}
+
 extern "C" int mllp_graph_set_path(mllp_graph_t* g, int path) {
     REQUIRE(g, "null graph");
     REQUIRE(path >= 0 && path <= 2, "path must be 0 (by size), 1 (generic / LDS-tiled sweeps) or 2 (fused latency-regime kernels)");

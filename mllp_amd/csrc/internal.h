@@ -167,6 +167,7 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
+int launch_spmm_tiled_bf16(const Tiled& tl, int n_dst, int n_src, const void* H_bf16, float* Y, hipStream_t s);
 struct ConvWs;
 int launch_fwd16_tiled(const Tiled& tl, int n_dst, int n_src, const float* conv_params, const ConvWs& w,
                        const float* x_src, const float* x_dst, float* h_out, hipStream_t s);

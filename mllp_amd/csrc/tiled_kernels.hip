@@ -104,11 +104,25 @@ __device__ __forceinline__ float4 lds_row(const float4* img, int byte_off) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(img) + byte_off);
 }
 
+// the same from a bf16 image (32-byte rows: `byte_off` is the fp32 offset, halved here): 4 channels of a lane, widened
+// exactly (a bf16 is the upper half of an fp32)
+__device__ __forceinline__ float4 lds_row_bf16(const float4* img, int byte_off) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(img) + (byte_off >> 1));
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+template <bool BF>
+__device__ __forceinline__ float4 lds_hrow(const float4* img, int byte_off) {
+    return BF ? lds_row_bf16(img, byte_off) : lds_row(img, byte_off);
+}
+
 // ABL: 4 = no walk (timing only), 16 = timing build: instead of the result Y receives cycle counters (s_memtime):
 //   row 2*tile      walkers, summed over waves: [0] wait at A, [1] stage (A..B), [4] walk, [5] total; loaders at [8..]:
 //                   [8] wait at B, [9] vmcnt wait + ds_write, [10] wait at A, [11] load issue, [13] total
 //   row 2*tile + 1  per walker wave: walk cycles [0..7], wait at A [8..15]
-template <int ABL>
+// BF: H is bf16 [n_src, 16] (opt-in `mllp_spmm_csr_bf16`: half the H bytes from L2, half the staging writes and row
+// reads in LDS, fp32 accumulation; the products differ from the fp32 path by the rounding of H to 8 mantissa bits)
+template <int ABL, bool BF = false>
 __global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __restrict__ Y) {
     __shared__ float4 Xs[T_CB * 4];     // 64 KB  staged column block of H
@@ -228,16 +242,17 @@ void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __rest
     } else if (wave >= W_NW) {
         // ------------------------------------------------ H loaders ----------------------------------
         const int lid = tid - W_NW * 64;
-        float4 px0, px1, px2, px3, px4, px5, px6, px7, px8, px9, px10, px11, px12, px13, px14, px15;
+        float4 px0 = {}, px1 = {}, px2 = {}, px3 = {}, px4 = {}, px5 = {}, px6 = {}, px7 = {}, px8 = {}, px9 = {}, px10 = {},
+               px11 = {}, px12 = {}, px13 = {}, px14 = {}, px15 = {};
         static_assert(W_XPT == 16, "the H-loader macros are written for 16 loads per thread");
-#define W_LDX(K) px##K = src_[(unsigned)min(lid + K * W_LT, c4_ - 1)];
-#define W_STX(K) Xs[lid + K * W_LT] = px##K;
+#define W_LDX(K) if (!BF || K < W_XPT / 2) px##K = src_[(unsigned)min(lid + K * W_LT, c4_ - 1)];
+#define W_STX(K) if (!BF || K < W_XPT / 2) Xs[lid + K * W_LT] = px##K;
 #define W_LOADX(B)                                                                                          \
     {                                                                                                       \
         const int b_ = min((B), nb - 1);                                                                    \
         const int c0_ = __builtin_amdgcn_readfirstlane(Bk[b_]) * T_CB;   /* wave-uniform: SGPR base */     \
-        const int c4_ = min(T_CB, t.n_src - c0_) * 4;                                                       \
-        const float4* src_ = reinterpret_cast<const float4*>(X + (size_t)c0_ * 16);                        \
+        const int c4_ = min(T_CB, t.n_src - c0_) * (BF ? 2 : 4);          /* 16-byte pieces of the block */  \
+        const float4* src_ = reinterpret_cast<const float4*>(X + (size_t)c0_ * (BF ? 8 : 16));             \
         W_LDX(0) W_LDX(1) W_LDX(2) W_LDX(3)                                                                  \
         W_LDX(4) W_LDX(5) W_LDX(6) W_LDX(7)                                                                  \
         W_LDX(8) W_LDX(9) W_LDX(10) W_LDX(11)                                                                \
@@ -305,10 +320,10 @@ void spmm_tiled_ws_kernel(TiledDev t, const float* __restrict__ X, float* __rest
             nB = Es[min(pB + 4, T_ECAP - 1)];                                                               \
             const int colA = pA < eA##P ? mA.x : 0, valA = pA < eA##P ? mA.y : 0;                           \
             const int colB = pB < eB##P ? mB.x : 0, valB = pB < eB##P ? mB.y : 0;                           \
-            const float4 x0 = lds_row(Xs, quad_bcast<0>(colA) + part16), x1 = lds_row(Xs, quad_bcast<1>(colA) + part16), \
-                         x2 = lds_row(Xs, quad_bcast<2>(colA) + part16), x3 = lds_row(Xs, quad_bcast<3>(colA) + part16); \
-            const float4 y0 = lds_row(Xs, quad_bcast<0>(colB) + part16), y1 = lds_row(Xs, quad_bcast<1>(colB) + part16), \
-                         y2 = lds_row(Xs, quad_bcast<2>(colB) + part16), y3 = lds_row(Xs, quad_bcast<3>(colB) + part16); \
+            const float4 x0 = lds_hrow<BF>(Xs, quad_bcast<0>(colA) + part16), x1 = lds_hrow<BF>(Xs, quad_bcast<1>(colA) + part16), \
+                         x2 = lds_hrow<BF>(Xs, quad_bcast<2>(colA) + part16), x3 = lds_hrow<BF>(Xs, quad_bcast<3>(colA) + part16); \
+            const float4 y0 = lds_hrow<BF>(Xs, quad_bcast<0>(colB) + part16), y1 = lds_hrow<BF>(Xs, quad_bcast<1>(colB) + part16), \
+                         y2 = lds_hrow<BF>(Xs, quad_bcast<2>(colB) + part16), y3 = lds_hrow<BF>(Xs, quad_bcast<3>(colB) + part16); \
             pk_fma4(__int_as_float(quad_bcast<0>(valA)), x0, cA0, cA1);                                     \
             pk_fma4(__int_as_float(quad_bcast<1>(valA)), x1, cA0, cA1);                                     \
             pk_fma4(__int_as_float(quad_bcast<2>(valA)), x2, cA0, cA1);                                     \
@@ -1268,6 +1283,16 @@ int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, flo
 #else
     hipLaunchKernelGGL(spmm_tiled_ws_kernel<0>, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, H, Y);
 #endif
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled");
+}
+
+// H: bf16 [n_src, 16]
+int launch_spmm_tiled_bf16(const Tiled& tl, int n_dst, int n_src, const void* H, float* Y, hipStream_t s) {
+    if (tl.n_tiles == 0) return MLLP_OK;
+    const TiledDev d = tiled_dev(tl, n_dst, n_src);
+    hipLaunchKernelGGL((spmm_tiled_ws_kernel<0, true>), dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d,
+                       reinterpret_cast<const float*>(H), Y);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "spmm_tiled_ws");
 }

@@ -113,6 +113,11 @@ def train_method(cfg, method_name, train_dataset, train_dict, out=print):
     ckpt_path = f"linear_program_{cfg.train_data_type}_{method_name}.ckpt"
     if rank == 0:
         out(f"Training the model weights for {method_name}...")
+    if str(cfg.get_default("dtype")).lower() not in ("f32", "fp32", "float32"):
+        raise NotImplementedError(
+            f"dtype: {cfg.get_default('dtype')!r}: the training step computes and stores fp32 (the reference's arithmetic, "
+            "north_star's 1e-5 parity bar); the opt-in bf16 feature image exists for the plain SpMM only "
+            "(LPBatch.spmm_bf16 / mllp_spmm_csr_bf16), where it measured slower than fp32 (DESIGN.md section 6)")
     device = torch.device(cfg.get_default("device"))
     if device.type != "cuda" or not torch.cuda.is_available():
         raise RuntimeError("this build runs the learned-LP path on MI355X through HIP only (device: 'cuda'); "

@@ -301,6 +301,19 @@ class LPBatch:
                                                 _lib.current_stream()))
         return out
 
+    def spmm_bf16(self, H: torch.Tensor, transpose=False, out: Optional[torch.Tensor] = None):
+        """Opt-in bf16 feature image: the same product with H given as torch.bfloat16 [n, 16] (fp32 values, fp32
+        accumulation, fp32 result).  Equals `spmm(H.float())` up to fp32 summation order, i.e. differs from the fp32
+        product by the rounding of H to bf16 (2^-8 relative per element) -- not the parity path.  Needs the tiled copy
+        (`enable_tiled(transpose)`)."""
+        n_in, n_out = (self.M, self.N) if transpose else (self.N, self.M)
+        assert H.is_cuda and H.dtype == torch.bfloat16 and H.is_contiguous() and tuple(H.shape) == (n_in, 16)
+        if out is None:
+            out = torch.empty(n_out, 16, device=H.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mllp_spmm_csr_bf16(self._h, int(transpose), _lib.ptr(H), _lib.ptr(out),
+                                                 _lib.current_stream()))
+        return out
+
     def tconv_workspace(self, dst_is_var, cin):
         n = c_int64()
         _lib.check(_lib.lib().mllp_tconv_workspace_floats(self._h, int(dst_is_var), cin, ctypes.byref(n)))

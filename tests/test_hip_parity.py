@@ -399,6 +399,35 @@ def test_tiled_spmm_equals_generic_and_oracle(LPBatch):
     close(got, dense_rows.spmm(H).cpu().numpy(), 2e-6, "multi-window segment")
 
 
+def test_bf16_feature_image_spmm(LPBatch):
+    """Opt-in `mllp_spmm_csr_bf16` (H as bf16, fp32 accumulate).  Two bounds, both
+    documented in include/mllp_hip.h: (a) against the fp32 kernel fed the SAME rounded features it is the same
+    arithmetic up to summation order (2e-6 of the tensor's max); (b) against the fp32 product of the unrounded features
+    the error is the rounding of H to 8 mantissa bits: 2^-8 of sum |a_ij| |h_j| per element (asserted elementwise).
+    Ragged tiles and blocks, both orientations; without the tiled copy the call is refused."""
+    from mllp_amd import _lib
+    from mllp_amd.graph import synthetic_batch
+    sb = synthetic_batch(n_inst=5, m=700, n=1300, mean_row_nnz=24.0, seed=31, chunk=2)
+    rng = np.random.default_rng(4)
+    for transpose in (False, True):
+        n_in = sb.M if transpose else sb.N
+        H = torch.tensor(rng.standard_normal((n_in, 16)).astype(np.float32), device="cuda")
+        Hb = H.to(torch.bfloat16).contiguous()
+        with pytest.raises(_lib.MllpError, match="tiled"):
+            sb.spmm_bf16(Hb, transpose=transpose)
+        assert sb.enable_tiled(transpose) is not None
+        got = sb.spmm_bf16(Hb, transpose=transpose).cpu().numpy()
+        same = sb.spmm(Hb.float().contiguous(), transpose=transpose).cpu().numpy()
+        close(got, same, 2e-6, f"bf16 image vs fp32 kernel on the rounded features (transpose={transpose})")
+        base = 3 if transpose else 0
+        ptr, idx, val = sb.export(base), sb.export(base + 1), sb.export(base + 2)
+        H64 = H.cpu().numpy().astype(np.float64)
+        exact = o2.spmm(ptr, idx, val.astype(np.float64), H64)
+        bound = o2.spmm(ptr, idx, np.abs(val).astype(np.float64), np.abs(H64)) * 2.0 ** -8 + 1e-6
+        assert np.all(np.abs(got - exact) <= bound), float(np.max(np.abs(got - exact) / bound))
+        sb.disable_tiled(transpose)
+
+
 def test_dropin_batched_graph_equals_per_graph(subset5, weights):
     """GNNModel on BipartiteData.batch([...]) (the __inc__ rule, reference methods.py:68-70) == per-graph calls;
     edge order of the input does not matter (the graph is re-sorted into CSR order when it is built)."""

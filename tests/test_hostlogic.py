@@ -296,6 +296,9 @@ def test_root_shims_and_driver_argument_errors(tmp_path, monkeypatch):
     y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'angleNet'\n")
     with pytest.raises(NotImplementedError, match="angleNet"):
         experiment.main(["--cfg", str(y)])
+    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\ndtype: bf16\nmethods:\n  - 'gs-topk'\n")
+    with pytest.raises(NotImplementedError, match="bf16"):       # stated, not silently computed in fp32
+        experiment.main(["--cfg", str(y)])
     y.write_text("train_data_type: 'twitch'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'gs-topk'\n")
     with pytest.raises(ValueError, match="Unknown training dataset"):
         experiment.main(["--cfg", str(y)])

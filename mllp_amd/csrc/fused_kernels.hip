@@ -736,10 +736,6 @@ struct Ent8 {
 };
 __device__ __forceinline__ void ent8_load(const ItemsDev& s, const RowSlot& r, int k0, Ent8& E) {
     const int last = max(s.nnz - 1, 0), d = r.stride, b = r.first + k0 * d;
-#ifdef MLLP_EXPERIMENT_NO_ENTRY_LOADS      // one-off timing experiment: what the strided entry loads cost
-    E.e0 = E.e1 = E.e2 = E.e3 = E.e4 = E.e5 = E.e6 = E.e7 = make_float2(0.25f, 0.5f);
-    return;
-#endif
     E.e0 = s.sax[min(b, last)];         E.e1 = s.sax[min(b + d, last)];
     E.e2 = s.sax[min(b + 2 * d, last)]; E.e3 = s.sax[min(b + 3 * d, last)];
     E.e4 = s.sax[min(b + 4 * d, last)]; E.e5 = s.sax[min(b + 5 * d, last)];

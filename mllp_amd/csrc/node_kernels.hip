@@ -621,7 +621,7 @@ __global__ __launch_bounds__(TOPM_T) void topm_metrics_kernel(const int* __restr
                                                               const float* __restrict__ logits,
                                                               const float* __restrict__ labels, float* __restrict__ out) {
     __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_need;
+    __shared__ unsigned s_prefix, s_need, s_wtot[4];
     __shared__ float s_red[4][TOPM_T / 64];
     __shared__ unsigned s_cnt[TOPM_T / 64];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -640,21 +640,52 @@ __global__ __launch_bounds__(TOPM_T) void topm_metrics_kernel(const int* __restr
         const int shift = pass * 8;
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
-        const unsigned prefix = s_prefix;
-        for (int i = tid; i < n; i += TOPM_T) {
-            const unsigned key = orderable(z[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        const unsigned prefix = s_prefix, need = s_need;
+        if (pass == 3) {
+            // top byte (sign + 7 exponent bits): a handful of distinct values, so plain LDS atomics serialise 64 lanes
+            // on one address (the kernel took 93 us for the Netlib batch, all of it here).  Wave-aggregated instead:
+            // one atomic per distinct bin of the wavefront.
+            for (int i0 = 0; i0 < n; i0 += TOPM_T) {
+                const int i = i0 + tid;
+                const bool have = i < n;
+                const unsigned bin = have ? (orderable(z[i]) >> 24) : 0u;
+                unsigned long long todo = __ballot(have);
+                while (todo) {
+                    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                    const unsigned long long same = __ballot(have && bin == b) & todo;
+                    if (lane == leader) atomicAdd(&hist[b], (unsigned)__popcll(same));
+                    todo &= ~same;
+                }
+            }
+        } else {
+            for (int i = tid; i < n; i += TOPM_T) {
+                const unsigned key = orderable(z[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = s_need, cum = 0u;
-            int bsel = 0;
-            for (int b = 255; b >= 0; --b) {
-                if (cum + hist[b] >= need) { bsel = b; break; }
-                cum += hist[b];
+        // the bin that holds the need-th largest key: suffix sums over the 256 bins in four wavefronts (one thread
+        // walking the bins took 256 dependent LDS reads per pass: most of the kernel's 90 us on the Netlib batch)
+        unsigned h = 0u, sfx = 0u;
+        if (tid < 256) {
+            h = hist[tid];
+            sfx = h;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_down(sfx, o, 64);
+                if (lane + o < 64) sfx += v;
             }
-            s_need = need - cum;
-            s_prefix = prefix | ((unsigned)bsel << shift);
+            if (lane == 0) s_wtot[wave] = sfx;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned above = 0u;
+            for (int w = wave + 1; w < 4; ++w) above += s_wtot[w];
+            const unsigned ge = sfx + above, gt = ge - h;      // keys of this prefix with bin >= tid / > tid
+            if (ge >= need && gt < need) {                     // exactly one bin
+                s_need = need - gt;
+                s_prefix = prefix | ((unsigned)tid << shift);
+            }
         }
         mask |= 255u << shift;
         __syncthreads();

@@ -1638,7 +1638,16 @@ __global__ __launch_bounds__(RT) void fused_reduce_kernel(ReduceArgs A, int n_co
     const float* src = A.stats[c] + tile * 256 + col;
     float v = 0.0f;
     int b = slice;
-    for (; b + 28 < A.nblk; b += 32) {      // eight partials in flight, fixed order
+    // the partials were written by other XCDs: every load is a 2 k-cycle trip to the Infinity Cache, so 32 of them are
+    // in flight at once (a thread of the 256-workgroup grid has 64 to add, in a fixed order)
+    for (; b + 124 < A.nblk; b += 128) {
+        float t[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t[q] = src[(size_t)(b + 4 * q) * STAT_FLOATS];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v += t[q];
+    }
+    for (; b + 28 < A.nblk; b += 32) {
         float t[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(b + 4 * q) * STAT_FLOATS];

@@ -755,16 +755,33 @@ int launch_bwdsrc16_tiled(const Tiled& tl, int n_rows, int n_cols, const float* 
 }
 
 // =================================================================================================
-// Attention backward, destination-major, in the tiled form: ds_i, dt_i, dq'_i and the destination-side input
-// gradient (sweep_kernels.hip::BwdDst16Op).  A row needs its record {q', gv, t, rowmax, 1/rowsum, ge, c} AND the
-// running {dq'[16], ds, dt}: 224 bytes per row, so the tile is 256 rows (56 KB) and the column block 768 sources
-// (48 KB of H).  Geometry (variant 4): 256 rows x 768 columns, 3072-entry windows.  256 rows are one bundle per
-// wave, so every wave takes 8 quads from the long end of the length-sorted order and 8 from the short end.
+// Attention backward, destination-major, ONE LANE PER ROW: ds_i, dt_i, dq'_i and the destination-side input gradient
+// (sweep_kernels.hip::BwdDst16Op).  The quad-per-row sweeps spend 3.5 wave instructions per nonzero (two dot products
+// reduced over the quad by DPP, an exp, masks); the first tiled version of this sweep (224 bytes of row state in LDS,
+// 256-row tiles) was no faster than the generic L2 gather (2.65 ms at 256 M nonzeros).  Here a lane OWNS a row of the
+// tile for all its column blocks: the record {q'[16], gv[16], t, rowmax, 1/rowsum, ge, c} and the running
+// {dq'[16], ds, dt} stay in its registers (no row state in LDS, no per-block row order), and one nonzero costs the lane
+// 24 packed FMAs + an exp.  Measured 1.84 ms at 256 M nonzeros (the walk is bound by LDS round trips: packed FMAs gave
+// 3 %, a bank-aware entry order 1 %; 12 walker wavefronts with 4 loader wavefronts were slower, 2.6 ms -- the loaders'
+// register sets no longer fit).
+//   * geometry (variant 4): 512 rows x 512 columns, 3072-entry windows; rows keep their order (lane l of walker w =
+//     row 64 w + l of the tile).  The entries of every 64-row chunk of a (tile, block) are stored by STEP: entry j of the
+//     rows that have one, in lane order -- step j of a wavefront reads one contiguous run, a lane's entry sits at
+//     S_j + (number of lower lanes that still have an entry): mbcnt of the ballot.  Lanes whose row has ended read a
+//     dummy entry (the image's zero row) and are masked.
+//   * roles as in the SpMM kernel: 8 walker wavefronts, 4 H loaders, 4 entry loaders; everything staged exists twice in
+//     LDS (2 x 32 KB of H, 2 x 24 KB of entries, 2 x 2 KB of row offsets): the loaders write image b + 1 from registers
+//     (loaded one or two blocks earlier) while the walkers walk image b -- one barrier per block.
+//   * the four 16-byte pieces of an H row are read in a per-lane rotation ((k + lane) & 3), which spreads the 16 lanes of
+//     a ds_read_b128 lane group over the bank quarters; q', gv and dq' are held in the same rotated order.
+//   * the rows' 16 x 16 epilogue (dx_i = Ws^T g_i + Pq^T dq'_i + ds_i Pb + dt_i Pt) runs 16 lanes per row from an LDS
+//     copy of dq' when all blocks are done.
 // =================================================================================================
-constexpr int D_R = 256;
-constexpr int D_CB = 768;
-constexpr int D_ECAP = 3 * T_THREADS;      // 3072 entries (24 KB) per window
-static_assert(D_CB * 4 == 3 * T_THREADS, "H block staged with 3 float4 per thread");
+constexpr int D_R = 512, D_CB = 512, D_ECAP = 3072;
+constexpr int D_XPT = (D_CB * 4) / W_LT;    // 8 float4 of H per H-loader thread
+constexpr int D_EPT = D_ECAP / W_LT;        // 12 entries per entry-loader thread
+constexpr int D_ZERO = D_CB * 64;           // byte offset of the image's zero row = column offset of the dummy entry
+static_assert(D_R == 8 * 64 && D_R == 2 * W_LT, "role split of the lane-per-row kernel");
 
 struct BwdDstTiledArgs {
     const float* __restrict__ X;        // [n_src, 16]
@@ -777,142 +794,251 @@ struct BwdDstTiledArgs {
     int accumulate;
 };
 
-__global__ __launch_bounds__(T_THREADS) void bwddst16_tiled_kernel(TiledDev t, BwdDstTiledArgs a) {
-    __shared__ float4 Xs[D_CB * 4];     // 48 KB  staged column block of H
-    __shared__ int2 Es[D_ECAP];         // 24 KB  entry segment (window)
-    __shared__ float4 Rq[D_R * 4];      // 16 KB  q' of the rows
-    __shared__ float4 Rg[D_R * 4];      // 16 KB  gv of the rows
-    __shared__ float4 Dq[D_R * 4];      // 16 KB  running dq'
-    __shared__ float4 Sc[D_R];          //  4 KB  {t, rowmax, rinv, ge}
-    __shared__ float4 Sd[D_R];          //  4 KB  {c, ds, dt, -}
-    __shared__ int Ps[D_R + 16];
-    __shared__ int Pm[D_R];
-    __shared__ int Sg[T_MAXB + 1];
-    __shared__ int Bk[T_MAXB];
+// 16-term dot product as eight packed FMAs: the two lanes of the result still have to be added
+__device__ __forceinline__ f32x2 pk_dot16(const float4& a0, const float4& a1, const float4& a2, const float4& a3,
+                                          const float4& b0, const float4& b1, const float4& b2, const float4& b3) {
+    f32x2 s = f32x2{a0.x, a0.y} * f32x2{b0.x, b0.y};
+    f32x2 u = f32x2{a2.x, a2.y} * f32x2{b2.x, b2.y};
+    s = __builtin_elementwise_fma(f32x2{a0.z, a0.w}, f32x2{b0.z, b0.w}, s);
+    u = __builtin_elementwise_fma(f32x2{a2.z, a2.w}, f32x2{b2.z, b2.w}, u);
+    s = __builtin_elementwise_fma(f32x2{a1.x, a1.y}, f32x2{b1.x, b1.y}, s);
+    u = __builtin_elementwise_fma(f32x2{a3.x, a3.y}, f32x2{b3.x, b3.y}, u);
+    s = __builtin_elementwise_fma(f32x2{a1.z, a1.w}, f32x2{b1.z, b1.w}, s);
+    u = __builtin_elementwise_fma(f32x2{a3.z, a3.w}, f32x2{b3.z, b3.w}, u);
+    return s + u;
+}
+
+__global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void bwddst16_lane_kernel(TiledDev t, BwdDstTiledArgs a) {
+    __shared__ float4 Xs[2][D_CB * 4 + 4];  // 2 x 32 KB  staged column blocks of H, each followed by a row of zeros
+    __shared__ int2 Es[2][D_ECAP + 1];      // 2 x 24 KB  entry windows, each followed by the dummy entry {zero row, 0}
+    __shared__ int PP[2][D_R + 8];          // offset of every row inside the segment; [D_R] = segment length
+    __shared__ int Sg[T_MAXB + 1];          // segment start of every block of this tile
+    __shared__ int Bk[T_MAXB];              // column-block id of every block of this tile
+    __shared__ int n_items_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int quad = lane >> 2, part = lane & 3;
     const int tile = xcd_tile(blockIdx.x, t.n_tiles);
     const int tb0 = t.tile_blk[tile], tb1 = t.tile_blk[tile + 1];
+    const int nb = tb1 - tb0;
     const int row0 = tile * D_R;
     const int n_rows = min(D_R, t.n_dst - row0);
+    const float* X = a.X;
 
-    {   // per-row inputs: 4 threads per row
-        const int r = tid >> 2;
-        const bool ok = r < n_rows;
-        const float* rp = a.rec + (size_t)(row0 + (ok ? r : 0)) * REC_W;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        Rq[tid] = ok ? ld4(rp + 4 * part) : z4;
-        Rg[tid] = ok ? ld4(rp + 16 + 4 * part) : z4;
-        Dq[tid] = z4;
-        if (part == 0) {
-            Sc[r] = ok ? ld4(rp + 32) : z4;
-            Sd[r] = make_float4(ok ? rp[36] : 0.f, 0.f, 0.f, 0.f);
-        }
+    // the walkers' row state (the other roles carry zeros)
+    const int rot = lane & 3;
+    float4 q0 = {}, q1 = {}, q2 = {}, q3 = {}, g0 = {}, g1 = {}, g2 = {}, g3 = {};
+    f32x2 d0l = {0.f, 0.f}, d0h = d0l, d1l = d0l, d1h = d0l, d2l = d0l, d2h = d0l, d3l = d0l, d3h = d0l;
+    float rt = 0.0f, rm = 0.0f, rinv = 0.0f, rge = 0.0f, rcc = 0.0f, ds = 0.0f, dt = 0.0f;
+    if (wave < W_NW && wave * 64 + lane < n_rows) {
+        const float* r = a.rec + (size_t)(row0 + wave * 64 + lane) * REC_W;
+        q0 = ld4(r + 4 * ((0 + rot) & 3)); q1 = ld4(r + 4 * ((1 + rot) & 3));
+        q2 = ld4(r + 4 * ((2 + rot) & 3)); q3 = ld4(r + 4 * ((3 + rot) & 3));
+        g0 = ld4(r + 16 + 4 * ((0 + rot) & 3)); g1 = ld4(r + 16 + 4 * ((1 + rot) & 3));
+        g2 = ld4(r + 16 + 4 * ((2 + rot) & 3)); g3 = ld4(r + 16 + 4 * ((3 + rot) & 3));
+        const float4 s0 = ld4(r + 32);
+        rt = s0.x; rm = s0.y; rinv = s0.z; rge = s0.w;
+        rcc = r[36];
     }
-    if (tid <= tb1 - tb0) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * D_R];
-    if (tid < tb1 - tb0) Bk[tid] = t.blk_id[tb0 + tid];
+
+    if (tid <= nb) Sg[tid] = t.ptr2[(size_t)(tb0 + tid) * D_R];
+    if (tid < nb) Bk[tid] = t.blk_id[tb0 + tid];
+    if (tid == 0) n_items_s = 0;
+    if (tid < 8) Xs[tid >> 2][D_CB * 4 + (tid & 3)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2) Es[tid][D_ECAP] = make_int2(D_ZERO, 0);
     __syncthreads();
-
-#define D_PREFETCH(S, TB)                                                                                   \
-    {                                                                                                       \
-        const int tbx_ = (TB);                                                                              \
-        const int c0_ = Bk[tbx_ - tb0] * D_CB;                                                              \
-        const int c4_ = min(D_CB, t.n_src - c0_) * 4;                                                       \
-        const float4* src_ = reinterpret_cast<const float4*>(a.X + (size_t)c0_ * 16);                      \
-        px##S##0 = src_[min(tid, c4_ - 1)];                                                                 \
-        px##S##1 = src_[min(tid + T_THREADS, c4_ - 1)];                                                     \
-        px##S##2 = src_[min(tid + 2 * T_THREADS, c4_ - 1)];                                                 \
-        seg0##S = Sg[tbx_ - tb0];                                                                           \
-        len##S = Sg[tbx_ - tb0 + 1] - seg0##S;                                                              \
-        pp##S = t.ptr2[(size_t)tbx_ * D_R + min(tid, D_R - 1)] - seg0##S;                                   \
-        pm##S = t.perm[(size_t)tbx_ * D_R + min(tid, D_R - 1)];                                             \
-        pe##S##0 = t.ent[seg0##S + min(tid, max(len##S - 1, 0))];                                           \
-        pe##S##1 = t.ent[seg0##S + min(tid + T_THREADS, max(len##S - 1, 0))];                               \
-        pe##S##2 = t.ent[seg0##S + min(tid + 2 * T_THREADS, max(len##S - 1, 0))];                           \
+    if (tid < nb) {
+        const int len = Sg[tid + 1] - Sg[tid];
+        atomicAdd(&n_items_s, max(1, (len + D_ECAP - 1) / D_ECAP));
     }
-#define D_DO_BLOCK(S, TB)                                                                                   \
+    __syncthreads();
+    const int n_items = nb > 0 ? n_items_s : 0;
+    const int n_even = (n_items + 1) & ~1;   // every role runs this many rounds (one barrier each)
+#define D_ADVANCE(B, W)                                                                                     \
     {                                                                                                       \
-        const int tbc_ = (TB);                                                                              \
-        __syncthreads();                                                                                    \
-        Xs[tid] = px##S##0; Xs[tid + T_THREADS] = px##S##1; Xs[tid + 2 * T_THREADS] = px##S##2;             \
-        Es[tid] = pe##S##0; Es[tid + T_THREADS] = pe##S##1; Es[tid + 2 * T_THREADS] = pe##S##2;             \
-        if (tid < D_R) {                                                                                    \
-            Ps[tid] = pp##S;                                                                                \
-            Pm[tid] = pm##S;                                                                                \
-        }                                                                                                   \
-        if (tid == 0) Ps[D_R] = len##S;                                                                     \
-        const int cur_seg0 = seg0##S, cur_len = len##S;                                                     \
-        __syncthreads();                                                                                    \
-        const int tb_next = min(tbc_ + 2, tb1 - 1);                                                         \
-        if (early) D_PREFETCH(S, tb_next)                                                                   \
-        walk(cur_seg0, cur_len);                                                                            \
-        if (!early) D_PREFETCH(S, tb_next)                                                                  \
+        W += D_ECAP;                                                                                        \
+        if (W >= Sg[B + 1] - Sg[B]) { W = 0; B += 1; }                                                      \
     }
 
-    // sorted position of this quad: 8 quads of a wave from the long end, 8 from the short end
-    const int kq = quad < 8 ? wave * 8 + quad : D_R - 1 - (wave * 8 + (quad - 8));
-    auto walk = [&](int cur_seg0, int cur_len) {
-        for (int w0 = 0; w0 < cur_len; w0 += D_ECAP) {
-            if (w0 > 0) {   // rare: segment longer than one window
-                __syncthreads();
-                for (int i = tid; i < min(D_ECAP, cur_len - w0); i += T_THREADS) Es[i] = t.ent[cur_seg0 + w0 + i];
-                __syncthreads();
-            }
-            const int w1 = w0 + D_ECAP;
-            const int s = max(Ps[kq], w0), e = min(Ps[kq + 1], w1);
-            if (s < e) {
-                const int rl = Pm[kq];
-                const float4 qp = Rq[rl * 4 + part], gv = Rg[rl * 4 + part], sc = Sc[rl];   // sc = {t, rowmax, rinv, ge}
-                float4 dq = Dq[rl * 4 + part], sd = Sd[rl];                                 // sd = {c, ds, dt, -}
-                int p = s - w0;
-                const int pe_ = e - w0;
-                for (; p + 1 < pe_; p += 2) {
-                    const int2 e0 = Es[p], e1 = Es[p + 1];
-                    const float4 x0 = Xs[(e0.x >> 4) + part], x1 = Xs[(e1.x >> 4) + part];
-                    const float a0 = __int_as_float(e0.y), a1 = __int_as_float(e1.y);
-                    const float l0 = fmaf(a0, sc.x, quad_sum4(dot4(qp, x0)));
-                    const float l1 = fmaf(a1, sc.x, quad_sum4(dot4(qp, x1)));
-                    const float al0 = exp_acc_t(l0 - sc.y) * sc.z, al1 = exp_acc_t(l1 - sc.y) * sc.z;
-                    const float dl0 = al0 * (quad_sum4(dot4(gv, x0)) + fmaf(a0, sc.w, sd.x));
-                    const float dl1 = al1 * (quad_sum4(dot4(gv, x1)) + fmaf(a1, sc.w, sd.x));
-                    sd.y += dl0;
-                    sd.z = fmaf(dl0, a0, sd.z);
-                    fma4(dl0, x0, dq);
-                    sd.y += dl1;
-                    sd.z = fmaf(dl1, a1, sd.z);
-                    fma4(dl1, x1, dq);
-                }
-                if (p < pe_) {
-                    const int2 e0 = Es[p];
-                    const float4 x0 = Xs[(e0.x >> 4) + part];
-                    const float a0 = __int_as_float(e0.y);
-                    const float l0 = fmaf(a0, sc.x, quad_sum4(dot4(qp, x0)));
-                    const float al0 = exp_acc_t(l0 - sc.y) * sc.z;
-                    const float dl0 = al0 * (quad_sum4(dot4(gv, x0)) + fmaf(a0, sc.w, sd.x));
-                    sd.y += dl0;
-                    sd.z = fmaf(dl0, a0, sd.z);
-                    fma4(dl0, x0, dq);
-                }
-                Dq[rl * 4 + part] = dq;
-                if (part == 0) Sd[rl] = sd;
-            }
+    if (n_items == 0) {
+        // a tile whose rows have no nonzeros: only the epilogue below
+    } else if (wave >= W_NW + W_LT / 64) {
+        // ------------------------------------------------ entry loaders ------------------------------
+        const int lid = tid - (W_NW * 64 + W_LT);
+        int2 peA0, peA1, peA2, peA3, peA4, peA5, peA6, peA7, peA8, peA9, peA10, peA11;
+        int2 peB0, peB1, peB2, peB3, peB4, peB5, peB6, peB7, peB8, peB9, peB10, peB11;
+        int2 ppA = make_int2(0, 0), ppB = ppA;
+        int lenA = 0, lenB = 0, segA = 0, segB = 0;
+        static_assert(D_EPT == 12, "the entry-loader macros are written for 12 loads per thread");
+#define D_LDE(S, K) pe##S##K = es_[(unsigned)min(lid + K * W_LT, wl_ - 1)];
+#define D_STE(S, K, BUF) Es[BUF][lid + K * W_LT] = pe##S##K;
+#define D_LOADE(S, B, W)                                                                                    \
+    {                                                                                                       \
+        const int b_ = min((B), nb - 1);                       /* past the end: refetch the last block */  \
+        const int w_ = (B) < nb ? (W) : 0;                                                                  \
+        seg##S = __builtin_amdgcn_readfirstlane(Sg[b_]);                                                    \
+        len##S = __builtin_amdgcn_readfirstlane(Sg[b_ + 1]) - seg##S;                                       \
+        const int wl_ = max(min(D_ECAP, len##S - w_), 1);                                                   \
+        const int2* es_ = t.ent + seg##S + w_;                                                              \
+        pp##S = reinterpret_cast<const int2*>(t.ptr2 + (size_t)(tb0 + b_) * D_R)[lid];                      \
+        D_LDE(S, 0) D_LDE(S, 1) D_LDE(S, 2) D_LDE(S, 3) D_LDE(S, 4) D_LDE(S, 5)                              \
+        D_LDE(S, 6) D_LDE(S, 7) D_LDE(S, 8) D_LDE(S, 9) D_LDE(S, 10) D_LDE(S, 11)                            \
+    }
+#define D_STAGEE(S, BUF)                                                                                    \
+    {                                                                                                       \
+        D_STE(S, 0, BUF) D_STE(S, 1, BUF) D_STE(S, 2, BUF) D_STE(S, 3, BUF) D_STE(S, 4, BUF) D_STE(S, 5, BUF) \
+        D_STE(S, 6, BUF) D_STE(S, 7, BUF) D_STE(S, 8, BUF) D_STE(S, 9, BUF) D_STE(S, 10, BUF) D_STE(S, 11, BUF) \
+        reinterpret_cast<int2*>(PP[BUF])[lid] = make_int2(pp##S.x - seg##S, pp##S.y - seg##S);              \
+        if (lid == 0) PP[BUF][D_R] = len##S;                                                                \
+    }
+        int be = 0, we = 0;          // item whose entries are loaded next
+        D_LOADE(A, be, we)
+        D_ADVANCE(be, we)
+        __builtin_amdgcn_sched_barrier(0);   // keep set A older than set B for the counted vmcnt waits
+        D_LOADE(B, be, we)
+        if (be < nb) D_ADVANCE(be, we)
+        D_STAGEE(A, 0)                       // item 0 -> image 0
+        D_LOADE(A, be, we)
+        if (be < nb) D_ADVANCE(be, we)
+        __syncthreads();                     // image 0 ready
+        // straight-line pairs (see spmm_tiled_ws_kernel): item it + 1 -> image 1 under the walk of image 0, ...
+        for (int it = 0; it < n_even; it += 2) {
+            D_STAGEE(B, 1)
+            D_LOADE(B, be, we)
+            if (be < nb) D_ADVANCE(be, we)
+            __syncthreads();
+            D_STAGEE(A, 0)
+            D_LOADE(A, be, we)
+            if (be < nb) D_ADVANCE(be, we)
+            __syncthreads();
         }
-    };
-
-    float4 pxA0, pxA1, pxA2, pxB0, pxB1, pxB2;
-    int2 peA0, peA1, peA2, peB0, peB1, peB2;
-    int ppA = 0, pmA = 0, seg0A = 0, lenA = 0, ppB = 0, pmB = 0, seg0B = 0, lenB = 0;
-    const bool early = wave < T_WAVES / 2;
-    if (tb0 < tb1) {
-        D_PREFETCH(A, tb0)
-        D_PREFETCH(B, min(tb0 + 1, tb1 - 1))
+#undef D_LDE
+#undef D_STE
+#undef D_LOADE
+#undef D_STAGEE
+    } else if (wave >= W_NW) {
+        // ------------------------------------------------ H loaders ----------------------------------
+        const int lid = tid - W_NW * 64;
+        float4 px0, px1, px2, px3, px4, px5, px6, px7;
+        static_assert(D_XPT == 8, "the H-loader macros are written for 8 loads per thread");
+#define D_LDX(K) px##K = src_[(unsigned)min(lid + K * W_LT, c4_ - 1)];
+#define D_STX(K, BUF) Xs[BUF][lid + K * W_LT] = px##K;
+#define D_LOADX(B)                                                                                          \
+    {                                                                                                       \
+        const int b_ = min((B), nb - 1);                                                                    \
+        const int c0_ = __builtin_amdgcn_readfirstlane(Bk[b_]) * D_CB;   /* wave-uniform: SGPR base */     \
+        const int c4_ = min(D_CB, t.n_src - c0_) * 4;                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(X + (size_t)c0_ * 16);                        \
+        D_LDX(0) D_LDX(1) D_LDX(2) D_LDX(3) D_LDX(4) D_LDX(5) D_LDX(6) D_LDX(7)                              \
     }
-    for (int tb = tb0; tb < tb1; tb += 2) {
-        D_DO_BLOCK(A, tb)
-        if (tb + 1 < tb1) D_DO_BLOCK(B, tb + 1)
+#define D_STAGEX(BUF)                                                                                       \
+    { D_STX(0, BUF) D_STX(1, BUF) D_STX(2, BUF) D_STX(3, BUF) D_STX(4, BUF) D_STX(5, BUF) D_STX(6, BUF) D_STX(7, BUF) }
+        int bx = 0, wx = 0;          // item whose H block is loaded next
+        D_LOADX(bx)
+        D_ADVANCE(bx, wx)
+        D_STAGEX(0)
+        D_LOADX(bx)
+        if (bx < nb) D_ADVANCE(bx, wx)
+        __syncthreads();                     // image 0 ready
+        for (int it = 0; it < n_even; it += 2) {
+            D_STAGEX(1)
+            D_LOADX(bx)
+            if (bx < nb) D_ADVANCE(bx, wx)
+            __syncthreads();
+            D_STAGEX(0)
+            D_LOADX(bx)
+            if (bx < nb) D_ADVANCE(bx, wx)
+            __syncthreads();
+        }
+#undef D_LDX
+#undef D_STX
+#undef D_LOADX
+#undef D_STAGEX
+    } else {
+        // ------------------------------------------------ walkers ------------------------------------
+        int bi = 0, w0 = 0;          // current item
+        __syncthreads();             // image 0 ready
+        for (int it = 0; it < n_even; ++it) {
+            if (it < n_items) {
+                const int buf = it & 1;
+                const int* Pb = PP[buf];
+                const int off = Pb[wave * 64 + lane];
+                const int len = Pb[wave * 64 + lane + 1] - off;
+                int n = len;                                                 // steps of this chunk: its longest row
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o, 64));
+                n = __builtin_amdgcn_readfirstlane(n);
+                if (n > 0) {
+                    int S = __builtin_amdgcn_readfirstlane(off) - w0;       // the chunk's first entry, window-relative
+                    const char* ebase = reinterpret_cast<const char*>(Es[buf]);
+                    const char* xbase = reinterpret_cast<const char*>(Xs[buf]);
+                    const char* c0 = xbase + ((0 + rot) & 3) * 16; const char* c1 = xbase + ((1 + rot) & 3) * 16;
+                    const char* c2 = xbase + ((2 + rot) & 3) * 16; const char* c3 = xbase + ((3 + rot) & 3) * 16;
+                    // entry of step J for this lane (the dummy entry when the row has ended or the window does not hold it)
+#define D_ENT(E, J)                                                                                         \
+    {                                                                                                       \
+        const bool on_ = (J) < len;                                                                         \
+        const unsigned long long m_ = __ballot(on_);                                                        \
+        const int p_ = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u)); \
+        S += __popcll(m_);                                                                                  \
+        const int i_ = (on_ && (unsigned)p_ < (unsigned)D_ECAP) ? p_ : D_ECAP;                              \
+        E = *reinterpret_cast<const int2*>(ebase + 8 * i_);                                                 \
     }
-#undef D_PREFETCH
-#undef D_DO_BLOCK
+#define D_ROWX(X_, E)                                                                                       \
+    X_##0 = *reinterpret_cast<const float4*>(c0 + E.x); X_##1 = *reinterpret_cast<const float4*>(c1 + E.x); \
+    X_##2 = *reinterpret_cast<const float4*>(c2 + E.x); X_##3 = *reinterpret_cast<const float4*>(c3 + E.x);
+                    // one nonzero: alpha recomputed from the saved rowmax / rowsum, dl, and the three accumulations
+#define D_FMA(E, X_)                                                                                        \
+    {                                                                                                       \
+        const float a_ = __int_as_float(E.y);                                                               \
+        const f32x2 ql_ = pk_dot16(q0, q1, q2, q3, X_##0, X_##1, X_##2, X_##3);                             \
+        const f32x2 gl_ = pk_dot16(g0, g1, g2, g3, X_##0, X_##1, X_##2, X_##3);                             \
+        const float l_ = fmaf(a_, rt, ql_.x + ql_.y);                                                       \
+        const float gx_ = gl_.x + gl_.y;                                                                    \
+        const float al_ = E.x != D_ZERO ? exp_acc(l_ - rm) * rinv : 0.0f;                                   \
+        const float dl_ = al_ * (gx_ + fmaf(a_, rge, rcc));                                                 \
+        ds += dl_;                                                                                          \
+        dt = fmaf(dl_, a_, dt);                                                                             \
+        pk_fma4(dl_, X_##0, d0l, d0h); pk_fma4(dl_, X_##1, d1l, d1h);                                       \
+        pk_fma4(dl_, X_##2, d2l, d2h); pk_fma4(dl_, X_##3, d3l, d3h);                                       \
+    }
+                    int2 e0, e1, e2, e3;
+                    float4 p0, p1, p2, p3, r0, r1, r2, r3;
+                    D_ENT(e0, 0) D_ENT(e1, 1) D_ENT(e2, 2) D_ENT(e3, 3)
+                    D_ROWX(p, e0)
+#define D_FENCE __builtin_amdgcn_sched_barrier(0);     // keep the issue order: next step's reads, THEN this step's math
+                    for (int j = 0;; j += 4) {
+                        D_ROWX(r, e1) D_FENCE D_FMA(e0, p) D_FENCE if (j + 1 >= n) break;
+                        D_ENT(e0, j + 4) D_FENCE
+                        D_ROWX(p, e2) D_FENCE D_FMA(e1, r) D_FENCE if (j + 2 >= n) break;
+                        D_ENT(e1, j + 5) D_FENCE
+                        D_ROWX(r, e3) D_FENCE D_FMA(e2, p) D_FENCE if (j + 3 >= n) break;
+                        D_ENT(e2, j + 6) D_FENCE
+                        D_ROWX(p, e0) D_FENCE D_FMA(e3, r) D_FENCE if (j + 4 >= n) break;
+                        D_ENT(e3, j + 7) D_FENCE
+                    }
+#undef D_FENCE
+#undef D_ENT
+#undef D_ROWX
+#undef D_FMA
+                }
+                D_ADVANCE(bi, w0)
+            }
+            __syncthreads();
+        }
+    }
+#undef D_ADVANCE
+    __syncthreads();
+    // ---- the rows' results -> LDS (the images are free now): dq' [D_R][16] over Xs[0], {ds, dt} over Es[0] ----
+    float4* Dq = Xs[0];
+    float2* Sd = reinterpret_cast<float2*>(Es[0]);
+    if (wave < W_NW) {
+        const int r = wave * 64 + lane;
+        Dq[r * 4 + ((0 + rot) & 3)] = make_float4(d0l.x, d0l.y, d0h.x, d0h.y);
+        Dq[r * 4 + ((1 + rot) & 3)] = make_float4(d1l.x, d1l.y, d1h.x, d1h.y);
+        Dq[r * 4 + ((2 + rot) & 3)] = make_float4(d2l.x, d2l.y, d2h.x, d2h.y);
+        Dq[r * 4 + ((3 + rot) & 3)] = make_float4(d3l.x, d3l.y, d3h.x, d3h.y);
+        Sd[r] = make_float2(ds, dt);
+    }
     __syncthreads();
 
     // ---- epilogue: 16 lanes per row (lane gl = input channel), 64 rows per pass ----
@@ -929,7 +1055,7 @@ __global__ __launch_bounds__(T_THREADS) void bwddst16_tiled_kernel(TiledDev t, B
     }
     for (int r = tid >> 4; r < n_rows; r += T_THREADS / 16) {
         const size_t row = (size_t)row0 + r;
-        const float4 sd = Sd[r];
+        const float2 sd = Sd[r];
         float da[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -937,13 +1063,13 @@ __global__ __launch_bounds__(T_THREADS) void bwddst16_tiled_kernel(TiledDev t, B
             da[4 * q] = v.x; da[4 * q + 1] = v.y; da[4 * q + 2] = v.z; da[4 * q + 3] = v.w;
         }
         a.dqp[row * 16 + gl] = select16(da, gl);
-        if (gl == 0) reinterpret_cast<float2*>(a.dsdt)[row] = make_float2(sd.y, sd.z);
+        if (gl == 0) reinterpret_cast<float2*>(a.dsdt)[row] = make_float2(sd.x, sd.y);
         if (a.dx_dst) {
             float gr[16];
             load_row16(a.g + row * 16, gr);
             float v = dot16(wsT, gr, 0.0f);
-            v = fmaf(sd.y, pb, v);
-            v = fmaf(sd.z, pt, v);
+            v = fmaf(sd.x, pb, v);
+            v = fmaf(sd.y, pt, v);
             v = dot16(pqT, da, v);
             float* dst = a.dx_dst + row * 16 + gl;
             *dst = a.accumulate ? *dst + v : v;
@@ -959,7 +1085,7 @@ int launch_bwddst16_tiled(const Tiled& tl, int n_dst, int n_src, const ConvWs& w
     d.ent = reinterpret_cast<const int2*>(tl.ent);
     d.n_tiles = tl.n_tiles; d.n_dst = n_dst; d.n_src = n_src;
     BwdDstTiledArgs a{x_src, w.rec, g, w.derived, w.dqp, w.dsdt, dx_dst, accumulate};
-    hipLaunchKernelGGL(bwddst16_tiled_kernel, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, a);
+    hipLaunchKernelGGL(bwddst16_lane_kernel, dim3((unsigned)tl.n_tiles), dim3(T_THREADS), 0, s, d, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwddst16_tiled");
 }

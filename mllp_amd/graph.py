@@ -17,10 +17,21 @@ from . import _lib
 from .data import LPInstance
 
 
+# variant 4 (a lane per row): the 16 sets of 4 lanes that read the same bank quarter in one LDS cycle -- lanes of one
+# ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32; MI355X_MICROARCH.md, LDS) with equal
+# (lane & 3), which is the rotation the kernel reads the four 16-byte pieces of an H row in
+_B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+LANE_GROUPS = [[l + h for l in grp if (l & 3) == r] for h in (0, 32) for grp in _B128_GROUPS for r in range(4)]
+
+
 def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="joint"):
     """Re-block one CSR orientation into the tiled layout of include/mllp_hip.h (mllp_graph_attach_tiled): row tiles
     of R rows x column blocks of CB columns, rows of a (tile, block) ordered by their entry count, entries of the
-    four rows of a ds_read_b128 lane group ordered jointly over (column mod 4).  Pure torch, any device (the CPU
+    four rows of a ds_read_b128 lane group ordered jointly over (column mod 4).  Variant 4 (destination-major
+    backward, one LANE per row) keeps the rows of a tile in their own order and stores the entries of every 64-row
+    chunk of a (tile, block) by step: entry j of the rows that have one, in row order -- at
+    chunk_start + sum_l' min(len_l', j) + #{l' < l : len_l' > j} for the chunk's l-th row.  Pure torch, any device (the CPU
     tests check it against the CSR it came from).  `entry_order="perrow"` keeps the simpler per-row round-robin (used
     by the CPU test that compares the two orders).  Returns (arrays, info) or None when the matrix does not qualify."""
     dev, nnz = idx.device, int(idx.numel())
@@ -45,8 +56,14 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
     key = (tile_blk[tl] + (blk - lo[tl]).long()) * R + (rows - tile * R).long()
     del rows, tile, tl
     counts = torch.bincount(key, minlength=n_tb * R)
+    lane_fixed = int(variant) == 4                      # a lane owns a row of the tile: rows keep their order
+    if lane_fixed and R % 64:
+        return None
     # inside every (tile, block): rows ordered by their entry count, descending (stable)
-    order = torch.argsort(counts.view(n_tb, R), dim=1, descending=True, stable=True)       # [n_tb, R] row of position k
+    if lane_fixed:
+        order = torch.arange(R, device=dev).expand(n_tb, R).contiguous()
+    else:
+        order = torch.argsort(counts.view(n_tb, R), dim=1, descending=True, stable=True)   # [n_tb, R] row of position k
     inv = torch.empty_like(order)
     inv.scatter_(1, order, torch.arange(R, device=dev).expand(n_tb, R))                    # position of row r
     sorted_counts = torch.gather(counts.view(n_tb, R), 1, order).reshape(-1)
@@ -65,7 +82,7 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
     # 64-byte H row covers a quarter of the 256-byte bank row, so four quads reading H rows with equal
     # (column mod 4) serialise (MI355X_MICROARCH.md, LDS).
     cls = ((idx - blk * CB) & 3).long()
-    joint = int(variant) in (0, 1) and R % 16 == 0 and entry_order != "perrow"
+    joint = int(variant) in (0, 1, 4) and R % 16 == 0 and entry_order != "perrow"
     if joint:
         # JOINT ordering of the four rows whose quads share a lane group ({0,3,5,6}, {1,2,4,7}, {8,11,13,14},
         # {9,10,12,15} of the 16 quads that walk positions 16 b .. 16 b + 15): at step p the four rows should
@@ -77,10 +94,13 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
         cnt.index_add_(0, pos_key * 4 + cls, torch.ones(nnz, dtype=torch.int32, device=dev))
         base = torch.cumsum(cnt, 0, dtype=torch.int64) - cnt              # start of (run, class) in canonical order
         order_c = torch.argsort(pos_key * 4 + cls, stable=True)            # canonical: (run, class, column)
-        QG = torch.tensor([[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]], device=dev)
-        c = cnt.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()          # [G, slot, class]
-        bs = base.view(n_tb, R // 16, 16, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()
-        p2 = ptr2[:-1].view(n_tb, R // 16, 16)[:, :, QG].reshape(-1, 4).contiguous()         # first slot of each run
+        if lane_fixed:  # a lane per row: the lanes of one ds_read_b128 lane group that read with the same rotation
+            QG, W = torch.tensor(LANE_GROUPS, device=dev), 64
+        else:
+            QG, W = torch.tensor([[0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]], device=dev), 16
+        c = cnt.view(n_tb, R // W, W, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()            # [G, slot, class]
+        bs = base.view(n_tb, R // W, W, 4)[:, :, QG].reshape(-1, 4, 4).contiguous()
+        p2 = ptr2[:-1].view(n_tb, R // W, W)[:, :, QG].reshape(-1, 4).contiguous()           # first slot of each run
         del cnt, base
         c0 = c.clone()
         rem = c.sum(-1)
@@ -100,11 +120,14 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
                 occ = (c0[:, i, :].gather(1, pk) - ci.gather(1, pk)).squeeze(1).long()
                 sel = act.nonzero().squeeze(1)
                 src = order_c[(bs[:, i, :].gather(1, pk).squeeze(1) + occ)[sel]]
-                dest[src] = p2[sel, i] + p
+                dest[src] = p if lane_fixed else p2[sel, i] + p          # lane_fixed: the step, placed below
                 ci.scatter_add_(1, pk, -act.to(ci.dtype)[:, None])
                 rem[:, i] -= act.to(rem.dtype)
                 used.scatter_(1, pk, used.gather(1, pk) | act[:, None])
-        del c, c0, bs, p2, rem, order_c, used, cls, ar, start_idx
+        del c, c0, bs, p2, rem, order_c, used, cls, start_idx
+        if lane_fixed:
+            step = dest
+        del ar
     else:
         # per-row ordering: round-robin over the classes, starting at the slot of the row's quad in its lane group
         g = ((pos_key & 7) >> 1)
@@ -123,7 +146,17 @@ def build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant=0, entry_order="join
         new_off[ordr] = ar
         del ordr
         dest = ptr2[pos_key] + (new_off - start_idx)
+        if lane_fixed:
+            step = new_off - start_idx
         del ar, start_idx, new_off
+    if lane_fixed:
+        # memory order = (tile-block, 64-row chunk, step inside the row, row): only existing entries, so the position of
+        # an entry is its rank under that key
+        K = int(step.max()) + 1
+        ordr = torch.argsort((torch.div(pos_key, 64, rounding_mode="floor") * K + step) * 64 + (pos_key & 63))
+        dest = torch.empty_like(ordr)
+        dest[ordr] = torch.arange(nnz, device=dev, dtype=torch.int64)
+        del step, ordr
     del pos_key
     # one padding entry behind the last: an empty (tile, block) at the very end still has a readable "first entry"
     ent = torch.zeros((nnz + 1, 2), dtype=torch.int32, device=dev)

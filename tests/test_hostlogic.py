@@ -312,8 +312,23 @@ def _random_csr(rng, m, n, kmax):
     return ptr, idx, val
 
 
+def _row_entries(ptr2, tb, R, variant):
+    """entry indices of every position of (tile, block) tb: contiguous runs (variants 0-3) or, variant 4, entry j of the
+    l-th row of a 64-row chunk at chunk_start + sum_l' min(len_l', j) + #{l' < l: len_l' > j} (build_tiled_arrays)"""
+    lens = np.diff(ptr2[tb * R:(tb + 1) * R + 1])
+    if variant != 4:
+        return [list(range(ptr2[tb * R + k], ptr2[tb * R + k + 1])) for k in range(R)]
+    out = []
+    for c0 in range(0, R, 64):
+        ln = lens[c0:c0 + 64]
+        start = int(ptr2[tb * R + c0])
+        for l in range(64):
+            out.append([start + int(np.minimum(ln, j).sum()) + int((ln[:l] > j).sum()) for j in range(int(ln[l]))])
+    return out
+
+
 @pytest.mark.parametrize("variant,R,CB,mult", [(0, 512, 1024, 64), (1, 512, 512, 64), (2, 512, 384, 160), (3, 256, 1024, 4),
-                                                (4, 256, 768, 64)])
+                                                (4, 512, 512, 64)])
 def test_tiled_reblocking_is_a_permutation_of_the_csr(variant, R, CB, mult):
     """mllp_amd.graph.build_tiled_arrays (the layout mllp_graph_attach_tiled borrows): every nonzero appears exactly
     once with its value, rows of a (tile, block) are ordered by entry count, offsets are consistent, entries carry the
@@ -333,10 +348,14 @@ def test_tiled_reblocking_is_a_permutation_of_the_csr(variant, R, CB, mult):
             p = perm[tb * R:(tb + 1) * R]
             assert sorted(p.tolist()) == list(range(R))                       # a permutation of the tile's rows
             lens = np.diff(ptr2[tb * R:(tb + 1) * R + 1])
-            assert np.all(np.diff(lens) <= 0)                                 # longest rows first
+            if variant == 4:
+                assert p.tolist() == list(range(R))                           # a lane owns a row: rows keep their order
+            else:
+                assert np.all(np.diff(lens) <= 0)                             # longest rows first
+            runs = _row_entries(ptr2, tb, R, variant)
             for k in range(R):
                 row = t * R + int(p[k])
-                for e in range(ptr2[tb * R + k], ptr2[tb * R + k + 1]):
+                for e in runs[k]:
                     off, bits = int(ent[e, 0]), ent[e, 1]
                     assert off % mult == 0 and 0 <= off // mult < CB
                     col = int(blk_id[tb]) * CB + off // mult

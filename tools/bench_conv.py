@@ -6,12 +6,13 @@ import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from mllp_amd.graph import synthetic_batch
-from oracle.pyg_restatement import flatten_state, init_state
+from mllp_amd.model import GNNModel, set_seed
 
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 b = synthetic_batch(n_inst)
-params = flatten_state(init_state(42, torch.float32)).cuda()
+set_seed(42)
+params = GNNModel().flat_parameters().detach().float().cuda()
 def timed(fn):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

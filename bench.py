@@ -323,6 +323,12 @@ def main():
             kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel, dst=constraints",
                             "ms": ms_bt, "alg_bytes": b_b, "GBps": b_b / ms_bt / 1e6,
                             "frac": b_b / ms_bt / 1e6 / HBM_PEAK_GBS})
+        # ... and with the lane-per-row destination-major sweep as well (variant 4 copy on the conv's own orientation)
+        if sb.enable_tiled(False, variant=4) and sb.enable_tiled(True, variant=4):
+            ms_bd = timed(conv_b, 6, warm=2)
+            kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel and bwddst16_lane_kernel, dst=constraints",
+                            "ms": ms_bd, "alg_bytes": b_b, "GBps": b_b / ms_bd / 1e6,
+                            "frac": b_b / ms_bd / 1e6 / HBM_PEAK_GBS})
         del ws, h, Hm, dh
         # layer-1 (one channel) conv: generic sweeps, then the LDS-tiled lane-per-row kernels (variant 3)
         cp1 = params0[144:288].contiguous()

@@ -284,10 +284,9 @@ class LPBatch:
         return info
 
     def enable_tiled_all(self):
-        """Attach every LDS-tiled copy (variants 0-3, both orientations; variant 4, the destination-major backward
-        sweep, measured no faster than the generic one and is left out): the throughput configuration for batches
-        of hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""
-        return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (0, 1, 2, 3)}
+        """Attach every LDS-tiled copy (variants 0-4, both orientations): the throughput configuration for batches of
+        hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""
+        return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (0, 1, 2, 3, 4)}
 
     def disable_tiled(self, transpose=False, variant=0):
         _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), int(variant), 0, 0, 0, c_void_p(0),

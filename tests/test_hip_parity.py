@@ -682,7 +682,7 @@ def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
             out.append(float(loss[0]))
         assert bool(getattr(sb, "_tiled", None)) == mode
         if mode:
-            assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (0, 1, 2, 3)]
+            assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (0, 1, 2, 3, 4)]
         losses[mode] = out
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-6, atol=0)
     auto = LPTrainer(flat_gpu, tiled_copies="auto")
@@ -709,7 +709,7 @@ def test_throughput_regime_32M_nonzeros(LPBatch, weights):
     close(Ya.cpu().numpy(), A @ Hn.double().cpu().numpy(), RTOL_ACT, "generic A H vs scipy at 34 M nnz")
     tr = LPTrainer(flat_gpu, lr=1e-3, tiled_copies="auto")
     loss1, logits1 = tr.step(sb)                                       # attaches the copies, then one fused step
-    assert sorted(sb._tiled) == [(t_, v) for t_ in (False, True) for v in (0, 1, 2, 3)]
+    assert sorted(sb._tiled) == [(t_, v) for t_ in (False, True) for v in (0, 1, 2, 3, 4)]
     close(logits1.cpu().numpy(), za.cpu().numpy(), RTOL_ACT, "trainer logits (tiled) vs generic")
     close(loss1.cpu().numpy(), la.cpu().numpy(), RTOL_ACT, "trainer loss (tiled) vs generic")
     Yb, Ybt = sb.spmm(Hn), sb.spmm(Hm, transpose=True)                 # tiled

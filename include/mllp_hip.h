@@ -129,7 +129,10 @@ int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf1
  * the source-major attention backward sweep (attach it to the orientation whose ROWS are the conv's source nodes;
  * the staged items are the 160-byte backward records, d_ent[.][0] = 160 * local column); variant 3 the layer-1
  * (one channel) forward and destination-major backward sweeps (staged items are scalars, d_ent[.][0] = 4 * local
- * column); variant 4 the destination-major attention backward sweep.  mllp_tconv_* / mllp_gnn_* use whichever
+ * column); variant 4 the destination-major attention backward sweep with one lane per row: d_perm is the
+ * identity (rows keep their order inside a tile, d_ptr2 their offsets) and the entries of every 64-row chunk of a
+ * (tile, block) are ordered by step -- entry j of the rows that have one, in row order -- instead of row by row
+ * (mllp_amd/graph.py::build_tiled_arrays builds every variant).  mllp_tconv_* / mllp_gnn_* use whichever
  * copies are attached and fall back to the generic sweeps (HIP as well) otherwise.                    */
 int mllp_tiled_geometry(int variant, int32_t* rows_per_tile, int32_t* cols_per_block, int32_t* bundle_capacity);
 int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int variant, int64_t n_tiles, int64_t n_tb,

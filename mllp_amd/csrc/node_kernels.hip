@@ -223,21 +223,25 @@ int stat_blocks_for(int64_t n_dst) {
     return (int)b;
 }
 
-__global__ __launch_bounds__(BLOCK) void param_stats16_kernel(int n, const float* __restrict__ g,
+// 1024-thread workgroups: the grid is capped at STAT_BLOCKS_MAX partials (one per CU), and with 256 threads that was
+// ONE wavefront per SIMD streaming 280 bytes per node with 24 dword loads in flight -- 1.25 ms for 2.5-5 M nodes, a
+// quarter of what HBM allows.  16 wavefronts per workgroup, 8 chunks per pass.
+constexpr int PS_BLOCK = 1024, PS_WAVES = PS_BLOCK / 64;
+__global__ __launch_bounds__(PS_BLOCK) void param_stats16_kernel(int n, const float* __restrict__ g,
                                                               const float* __restrict__ x, const float* __restrict__ Z,
                                                               const float* __restrict__ aux,
                                                               const float* __restrict__ dqp,
                                                               const float* __restrict__ dsdt, float* __restrict__ out) {
-    __shared__ float sh[4][STAT_FLOATS];
+    __shared__ float sh[4][STAT_FLOATS];      // the 16 wavefronts fold into it four at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     f32x4 acc[STAT_TILES];
 #pragma unroll
     for (int i = 0; i < STAT_TILES; ++i) acc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     // a pass covers CH consecutive chunks of 4 nodes: all loads of the pass are issued before its MFMAs
-    constexpr int CH = 4;
+    constexpr int CH = 8;
     const int npass = (n + 4 * CH - 1) / (4 * CH);
-    for (int ps = blockIdx.x * 4 + wave; ps < npass; ps += gridDim.x * 4) {
+    for (int ps = blockIdx.x * PS_WAVES + wave; ps < npass; ps += gridDim.x * PS_WAVES) {
         float ag[CH], adq[CH], asc[CH], bx[CH], bz[CH], be[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -265,53 +269,75 @@ __global__ __launch_bounds__(BLOCK) void param_stats16_kernel(int n, const float
             acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(asc[c], be[c], acc[6], 0, 0, 0);
         }
     }
+    // fixed order: wavefronts 0-3 store, 4-7 / 8-11 / 12-15 add in turn
+    for (int round = 0; round < PS_WAVES / 4; ++round) {
+        if ((wave >> 2) == round) {
 #pragma unroll
-    for (int i = 0; i < STAT_TILES; ++i)
+            for (int i = 0; i < STAT_TILES; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sh[wave][i * 256 + (kq * 4 + j) * 16 + r] = acc[i][j];
-    __syncthreads();
-    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK)
+                for (int j = 0; j < 4; ++j) {
+                    float* d = &sh[wave & 3][i * 256 + (kq * 4 + j) * 16 + r];
+                    *d = round == 0 ? acc[i][j] : *d + acc[i][j];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += PS_BLOCK)
         out[(size_t)blockIdx.x * STAT_FLOATS + i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
 }
 
 // cin = 1: node features, Z, dq' are scalars; 16 lanes per node (lane o owns g_o); same tile layout out.
-__global__ __launch_bounds__(BLOCK) void param_stats1_kernel(int n, const float* __restrict__ g,
+// (1024 threads and four nodes in flight per 16-lane group for the same reason as param_stats16_kernel)
+__global__ __launch_bounds__(PS_BLOCK) void param_stats1_kernel(int n, const float* __restrict__ g,
                                                              const float* __restrict__ x, const float* __restrict__ Z,
                                                              const float* __restrict__ aux,
                                                              const float* __restrict__ dqp,
                                                              const float* __restrict__ dsdt, float* __restrict__ out) {
-    __shared__ float sh[16][16][12];
+    constexpr int NG = PS_BLOCK / 16;       // 16-lane groups per workgroup
+    __shared__ float sh[NG][16][12];
     const int grp = threadIdx.x >> 4, o = threadIdx.x & 15;
     float a[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) a[i] = 0.0f;
-    for (int node = blockIdx.x * 16 + grp; node < n; node += gridDim.x * 16) {
-        const float go = g[(size_t)node * 16 + o];
-        const float xv = x[node], zv = Z[node], dq = dqp[node];
-        const float2 sd = reinterpret_cast<const float2*>(dsdt)[node];
-        const float4 ax = reinterpret_cast<const float4*>(aux)[node];
-        a[0] = fmaf(go, xv, a[0]);      // T0[o][0]
-        a[1] = fmaf(go, zv, a[1]);      // T1[o][0]
-        a[2] += go;                     // T2[o][0]
-        a[3] = fmaf(go, ax.w, a[3]);    // T2[o][1]
-        a[4] = fmaf(go, ax.x, a[4]);    // T2[o][2]
-        a[5] = fmaf(dq, xv, a[5]);      // T3[0][0]
-        a[6] += dq;                     // T4[0][0]
-        a[7] = fmaf(sd.x, xv, a[7]);    // T5[0][0]
-        a[8] = fmaf(sd.y, xv, a[8]);    // T5[1][0]
-        a[9] += sd.x;                   // T6[0][0]
-        a[10] += sd.y;                  // T6[1][0]
+    const int stride = gridDim.x * NG;
+    for (int node0 = blockIdx.x * NG + grp; node0 < n; node0 += 4 * stride) {
+        float go[4], xv[4], zv[4], dq[4];
+        float2 sd[4];
+        float4 ax[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {        // all loads of the four nodes leave before the first is used
+            const int node = min(node0 + k * stride, n - 1);
+            go[k] = g[(size_t)node * 16 + o];
+            xv[k] = x[node]; zv[k] = Z[node]; dq[k] = dqp[node];
+            sd[k] = reinterpret_cast<const float2*>(dsdt)[node];
+            ax[k] = reinterpret_cast<const float4*>(aux)[node];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (node0 + k * stride >= n) break;
+            a[0] = fmaf(go[k], xv[k], a[0]);        // T0[o][0]
+            a[1] = fmaf(go[k], zv[k], a[1]);        // T1[o][0]
+            a[2] += go[k];                          // T2[o][0]
+            a[3] = fmaf(go[k], ax[k].w, a[3]);      // T2[o][1]
+            a[4] = fmaf(go[k], ax[k].x, a[4]);      // T2[o][2]
+            a[5] = fmaf(dq[k], xv[k], a[5]);        // T3[0][0]
+            a[6] += dq[k];                          // T4[0][0]
+            a[7] = fmaf(sd[k].x, xv[k], a[7]);      // T5[0][0]
+            a[8] = fmaf(sd[k].y, xv[k], a[8]);      // T5[1][0]
+            a[9] += sd[k].x;                        // T6[0][0]
+            a[10] += sd[k].y;                       // T6[1][0]
+        }
     }
 #pragma unroll
     for (int i = 0; i < 11; ++i) sh[grp][o][i] = a[i];
     __syncthreads();
     float* dst = out + (size_t)blockIdx.x * STAT_FLOATS;
-    for (int i = threadIdx.x; i < STAT_FLOATS; i += BLOCK) dst[i] = 0.0f;
+    for (int i = threadIdx.x; i < STAT_FLOATS; i += PS_BLOCK) dst[i] = 0.0f;
     __syncthreads();
     if (threadIdx.x < 16 * 11) {
         const int oo = threadIdx.x / 11, i = threadIdx.x % 11;
         float v = 0.0f;
-        for (int gq = 0; gq < 16; ++gq) v += sh[gq][oo][i];
+        for (int gq = 0; gq < NG; ++gq) v += sh[gq][oo][i];
         if (i == 0) dst[0 * 256 + oo * 16 + 0] = v;
         else if (i == 1) dst[1 * 256 + oo * 16 + 0] = v;
         else if (i <= 4) dst[2 * 256 + oo * 16 + (i - 2)] = v;
@@ -329,10 +355,10 @@ __global__ __launch_bounds__(BLOCK) void param_stats1_kernel(int n, const float*
 int launch_param_stats(int cin, int64_t n_dst, const ConvWs& w, const float* x_dst, const float* g, hipStream_t s) {
     const int blocks = stat_blocks_for(n_dst);
     if (cin == 16)
-        hipLaunchKernelGGL(param_stats16_kernel, dim3(blocks), dim3(BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux,
+        hipLaunchKernelGGL(param_stats16_kernel, dim3(blocks), dim3(PS_BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux,
                            w.dqp, w.dsdt, w.stats);
     else
-        hipLaunchKernelGGL(param_stats1_kernel, dim3(blocks), dim3(BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux, w.dqp,
+        hipLaunchKernelGGL(param_stats1_kernel, dim3(blocks), dim3(PS_BLOCK), 0, s, (int)n_dst, g, x_dst, w.Z, w.aux, w.dqp,
                            w.dsdt, w.stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "param_stats");

@@ -138,25 +138,28 @@ __global__ __launch_bounds__(BLOCK) void bwd_pre_kernel(int n, ConvParams p, con
                                                         const float* __restrict__ xd, const float* __restrict__ qp,
                                                         const float* __restrict__ t, const float* __restrict__ Z,
                                                         const float* __restrict__ aux, float* __restrict__ rec) {
-    const int node = blockIdx.x * 16 + (threadIdx.x >> 4);
+    // grid-stride over groups of 16 nodes: the lane's weights (a row of Wv^T, we_k, bv_k) are loaded once, and the
+    // masked g row every lane needs (gv_k = sum_o g_o Wv[o][k]) is gathered from the 16 lanes of the group by DPP row
+    // broadcasts instead of two more 64-byte row loads per lane (0.80 -> ... ms for 5.1 M nodes)
     const int k = threadIdx.x & 15;
-    if (node >= n) return;
+    float wvt[16];
+    if (CIN == 16) load_row16(D + OFF_WVT + k * 16, wvt);
+    const float wek = p.we[k], bvk = p.bv[k];
+    for (int node = blockIdx.x * 16 + (threadIdx.x >> 4); node < n; node += gridDim.x * 16) {
     const float hk = h[(size_t)node * 16 + k];
     const float gk = hk > 0.0f ? dh[(size_t)node * 16 + k] : 0.0f;
-    float hr[16], gr[16];
-    if (CIN == 16) {   // every lane needs the whole masked g row (gv_k = sum_o g_o Wv[o][k]): read it before the store
-        load_row16(h + (size_t)node * 16, hr);
-        load_row16(dh + (size_t)node * 16, gr);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) gr[o] = hr[o] > 0.0f ? gr[o] : 0.0f;
+    float gr[16];
+    if (CIN == 16) {
+        gr[0] = dpp_mov<0x150>(gk);  gr[1] = dpp_mov<0x151>(gk);  gr[2] = dpp_mov<0x152>(gk);  gr[3] = dpp_mov<0x153>(gk);
+        gr[4] = dpp_mov<0x154>(gk);  gr[5] = dpp_mov<0x155>(gk);  gr[6] = dpp_mov<0x156>(gk);  gr[7] = dpp_mov<0x157>(gk);
+        gr[8] = dpp_mov<0x158>(gk);  gr[9] = dpp_mov<0x159>(gk);  gr[10] = dpp_mov<0x15A>(gk); gr[11] = dpp_mov<0x15B>(gk);
+        gr[12] = dpp_mov<0x15C>(gk); gr[13] = dpp_mov<0x15D>(gk); gr[14] = dpp_mov<0x15E>(gk); gr[15] = dpp_mov<0x15F>(gk);
     }
     dh[(size_t)node * 16 + k] = gk;
     const float4 ax = reinterpret_cast<const float4*>(aux)[node];  // {u, rowmax, rinv, S}
-    const float ge = row16_sum(gk * p.we[k]);
-    const float gb = row16_sum(gk * p.bv[k]);
+    const float ge = row16_sum(gk * wek);
+    const float gb = row16_sum(gk * bvk);
     if (CIN == 16) {
-        float wvt[16];
-        load_row16(D + OFF_WVT + k * 16, wvt);
         const float gv = dot16(wvt, gr, 0.0f);
         const float Dn = row16_sum(gv * Z[(size_t)node * 16 + k]) + gb * ax.w + ge * ax.x;
         const float cc = gb - Dn;
@@ -192,12 +195,13 @@ __global__ __launch_bounds__(BLOCK) void bwd_pre_kernel(int n, ConvParams p, con
             rec[(size_t)node * 8 + k] = v;
         }
     }
+    }
 }
 
 int launch_bwd_pre(int64_t n_dst, int cin, const float* conv_params, const ConvWs& w, const float* x_dst,
                      const float* h_out, float* dh, hipStream_t s) {
     if (n_dst == 0) return MLLP_OK;
-    const int64_t blocks = (n_dst + 15) / 16;
+    const int64_t blocks = std::min<int64_t>((n_dst + 15) / 16, 8192);      // grid-stride: 16 nodes per pass and block
     ConvParams p = conv_params_at(conv_params, cin);
     if (cin == 16)
         hipLaunchKernelGGL(bwd_pre_kernel<16>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, (int)n_dst, p, w.derived,

@@ -2,7 +2,7 @@
 """Per-parameter-group comparison of the fused and the generic whole-model paths (debugging aid)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 import scipy.sparse as sp
 from mllp_amd.data import LPInstance, load_packed

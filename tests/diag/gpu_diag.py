@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 from mllp_amd import _lib  # noqa: E402
 from mllp_amd.data import SUBSET5, load_packed  # noqa: E402

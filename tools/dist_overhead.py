@@ -7,12 +7,12 @@ torch.cuda.set_device(0)
 from mllp_amd.data import load_packed
 from mllp_amd.graph import LPBatch
 from mllp_amd.trainer import LPTrainer
-from oracle.pyg_restatement import flatten_state, init_state
+from mllp_amd.model import GNNModel, set_seed
 
 PG_FIRST = "--pg-first" in sys.argv
 if PG_FIRST:
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-params0 = flatten_state(init_state(42, torch.float32)).cuda()
+params0 = (set_seed(42), GNNModel().flat_parameters().detach().float().cuda())[1]
 batch = LPBatch.from_instances(load_packed())
 
 

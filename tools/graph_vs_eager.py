@@ -8,9 +8,9 @@ sys.path.insert(0, ROOT)
 from mllp_amd.data import load_packed
 from mllp_amd.graph import LPBatch
 from mllp_amd.trainer import LPTrainer
-from oracle.pyg_restatement import flatten_state, init_state
+from mllp_amd.model import GNNModel, set_seed
 
-params = flatten_state(init_state(42, torch.float32)).cuda()
+params = (set_seed(42), GNNModel().flat_parameters().detach().float().cuda())[1]
 insts = sorted(load_packed(), key=lambda i: i.nnz)
 for inst in (insts[0], insts[len(insts) // 2], insts[-1]):
     b = LPBatch.from_instances([inst])

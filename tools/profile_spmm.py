@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from mllp_amd.graph import synthetic_batch  # noqa: E402
-from oracle.pyg_restatement import flatten_state, init_state  # noqa: E402
+from mllp_amd.model import GNNModel, set_seed  # noqa: E402
 
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -23,7 +23,7 @@ for _ in range(reps):
     b.spmm(H, out=Y)
     b.spmm(Ht, transpose=True, out=Yt)
 if which in ("conv", "all"):
-    params = flatten_state(init_state(42, torch.float32)).cuda()
+    params = (set_seed(42), GNNModel().flat_parameters().detach().float().cuda())[1]
     cp = params[1392:1392 + 1104].contiguous()
     ws = b.tconv_workspace(False, 16)
     for _ in range(reps):

@@ -11,12 +11,12 @@ sys.path.insert(0, ROOT)
 from mllp_amd.data import load_packed  # noqa: E402
 from mllp_amd.graph import LPBatch, synthetic_batch  # noqa: E402
 from mllp_amd.trainer import LPTrainer  # noqa: E402
-from oracle.pyg_restatement import flatten_state, init_state  # noqa: E402
+from mllp_amd.model import GNNModel, set_seed  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "netlib"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_syn = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-params = flatten_state(init_state(42, torch.float32)).cuda()
+params = (set_seed(42), GNNModel().flat_parameters().detach().float().cuda())[1]
 if which == "netlib":
     batch = LPBatch.from_instances(load_packed())
 else:

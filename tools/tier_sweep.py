@@ -9,9 +9,9 @@ sys.path.insert(0, ROOT)
 from mllp_amd.data import load_packed
 from mllp_amd.graph import LPBatch
 from mllp_amd.trainer import LPTrainer
-from oracle.pyg_restatement import flatten_state, init_state
+from mllp_amd.model import GNNModel, set_seed
 
-params = flatten_state(init_state(42, torch.float32)).cuda()
+params = (set_seed(42), GNNModel().flat_parameters().detach().float().cuda())[1]
 insts = load_packed()
 for tw, tb in ((0, 0), (8, 256), (16, 256), (32, 256), (64, 256), (16, 128), (32, 128), (32, 512), (128, 512)):
     b = LPBatch.from_instances(insts, tier_wave=tw, tier_block=tb)

@@ -12,10 +12,10 @@ step() {  # name, seconds, command...
 for s in "$@"; do
   case $s in
     tests) step pytest_gpu 900 python -m pytest tests -m gpu -x -q ;;
-    diagfull) step diag_full 300 python tools/gpu_diag.py full ;;
+    diagfull) step diag_full 300 python tests/diag/gpu_diag.py full ;;
     bench) step bench 900 python bench.py --steps 50 --warmup 5 ;;
     benchquick) step benchquick 600 python bench.py --steps 20 --warmup 3 --synthetic-instances 32 ;;
-    diag) step diag_subset 300 python tools/gpu_diag.py subset ; step diag_subset_t 300 python tools/gpu_diag.py subset 4 16 ;;
+    diag) step diag_subset 300 python tests/diag/gpu_diag.py subset ; step diag_subset_t 300 python tests/diag/gpu_diag.py subset 4 16 ;;
     prof) mkdir -p gpurun_out/prof_netlib gpurun_out/prof_syn; export TMPDIR=/tmp
           step prof_netlib 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_netlib -- python3 tools/profile_step.py netlib 10
           step prof_syn 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_syn -- python3 tools/profile_step.py synthetic 5 32 ;;

@@ -973,15 +973,20 @@ __device__ __forceinline__ void bwd16_fetch(const BwdJob16& J, const RowSlot& r,
 // tiles of a wavefront in the destination-major backward sweep
 constexpr int TB_G = 0, TB_X = 1, TB_Z = 2, TB_DQ = 3, TB_SC = 4, TB_E = 5, TB_N = 6;
 
-__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const RowSlot& r, BwdRow& rd, int2& en,
-                                          const SlotReq& qn, RowSlot& rn, int part,
+// itn: the wavefront's next item (-1: none).  Its row pointers are requested BEHIND this item's first gathers: requested
+// in front of them (by the caller), they were the youngest loads when the first use of the prefetched row data made
+// hipcc wait with vmcnt(0) -- a full round trip at the top of every item.
+__device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, const PartTiers& P, const RowSlot& r,
+                                          BwdRow& rd, int2& en, int itn, RowSlot& rn, int part,
                                           int lane, float* merge_lds, float* tiles, f32x4m (&acc)[STAT_TILES]) {
     const bool have = r.row >= 0;
     const bool writer = r.writer;
-    const int xpos = (rd.x.x > 0.0f ? 1 : 0) | (rd.x.y > 0.0f ? 2 : 0) | (rd.x.z > 0.0f ? 4 : 0) | (rd.x.w > 0.0f ? 8 : 0);
     const int n_mine = FUSED_ABL(1) ? 0 : slot_count(r);
     Gather4 gt;
     gather4_issue(J.s, J.x_src, r, n_mine, 0, part, en, gt);      // the first gathers leave before anything else
+    SlotReq qn = item_request<4>(J.s, P, max(itn, 0), lane);       // consumed behind the sweep
+    if (itn < 0) qn.row = -1;
+    const int xpos = (rd.x.x > 0.0f ? 1 : 0) | (rd.x.y > 0.0f ? 2 : 0) | (rd.x.z > 0.0f ? 4 : 0) | (rd.x.w > 0.0f ? 8 : 0);
     float4 qp, gv;
     float t, m, rinv, ge, cc;
     {   // everything of the row that the sweep does not need stays in the tiles G, X, Z, E until the statistics
@@ -1008,13 +1013,6 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         const float Dn = quad_sum(dot4(gv, Zn)) + gb * ax.w + ge * ax.x;
         cc = gb - Dn;
         m = ax.y; rinv = ax.z;
-        if (writer && J.rec && !FUSED_ABL(8)) {
-            float* rr = J.rec + (size_t)r.row * REC_W;
-            *reinterpret_cast<float4*>(rr + 4 * part) = qp;
-            *reinterpret_cast<float4*>(rr + 16 + 4 * part) = gv;
-            if (part == 0) *reinterpret_cast<float4*>(rr + 32) = make_float4(t, m, rinv, ge);
-            if (part == 1) *reinterpret_cast<float4*>(rr + 36) = make_float4(cc, 0.0f, 0.0f, 0.0f);
-        }
     }
     BwdState st;
     st.dq = f4zero(); st.ds = 0.0f; st.dt = 0.0f;
@@ -1023,6 +1021,15 @@ __device__ __forceinline__ void bwd16_row(const BwdJob16& J, const BwdW16& W, co
         k0 += 4;
         if (!__any(k0 < n_mine)) break;
         gather4_issue(J.s, J.x_src, r, n_mine, k0, part, en, gt);
+    }
+    // the record leaves behind the sweep: stored in front of it, the sweep's gather waits (vmcnt(0)) waited for the
+    // stores' acknowledgements as well
+    if (writer && J.rec && !FUSED_ABL(8)) {
+        float* rr = J.rec + (size_t)r.row * REC_W;
+        *reinterpret_cast<float4*>(rr + 4 * part) = qp;
+        *reinterpret_cast<float4*>(rr + 16 + 4 * part) = gv;
+        if (part == 0) *reinterpret_cast<float4*>(rr + 32) = make_float4(t, m, rinv, ge);
+        if (part == 1) *reinterpret_cast<float4*>(rr + 36) = make_float4(cc, 0.0f, 0.0f, 0.0f);
     }
     // the next item's row data and first entries travel while this one finishes
     rn = slot_make(qn);                // the next item's row pointers were requested when this item started
@@ -1148,7 +1155,7 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
             bwd16_fetch(J, r, part, rd);
             int2 en = first_entries<4>(J.s, r, part);
             RowSlot rn;
-            bwd16_row(J, Ws_[j], r, rd, en, empty_request(), rn, part, lane, merge_lds, tiles, acc);
+            bwd16_row(J, Ws_[j], P, r, rd, en, -1, rn, part, lane, merge_lds, tiles, acc);
         }
         WaveList wl = wave_list(J.s, px, gw);
         for (int c0 = 0; c0 < wl.L; c0 += 64) {
@@ -1160,9 +1167,8 @@ __global__ __launch_bounds__(FT) void fused_bwd16_kernel(BwdLaunch16 A) {
             int2 en = first_entries<4>(J.s, r, part);
             for (int k = 0; it >= 0; ++k) {
                 const int itn = wave_list_get(wl, k + 1);
-                const SlotReq qn = itn >= 0 ? item_request<4>(J.s, P, itn, lane) : empty_request();
                 RowSlot rn;
-                bwd16_row(J, Ws_[j], r, rd, en, qn, rn, part, lane, merge_lds, tiles, acc);
+                bwd16_row(J, Ws_[j], P, r, rd, en, itn, rn, part, lane, merge_lds, tiles, acc);
                 r = rn;
                 it = itn;
             }

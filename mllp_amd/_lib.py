@@ -36,6 +36,10 @@ _PROTOTYPES = {
     "mllp_graph_set_path": (c_int, [c_void_p, c_int]),
     "mllp_spmm_csr_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mllp_spmm_csr_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mllp_angle_num_params": (c_int, [c_int, POINTER(c_int64)]),
+    "mllp_angle_workspace_floats": (c_int, [c_int64, c_int, POINTER(c_int64)]),
+    "mllp_angle_forward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mllp_angle_backward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mllp_tiled_geometry": (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "mllp_graph_attach_tiled": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),

@@ -25,6 +25,7 @@ HOT_PATH_DEFAULTS = {
     "resume": False,         # resume from linear_program_<data>_<method>.ckpt if present
     "tiled_copies": "auto",  # LDS-tiled copies of the batch for the large-batch kernels: True | False | 'auto' (>= 32 M nonzeros)
     "use_hip_graph": "auto", # capture the training step into a hipGraph: True | False | 'auto' (= False: eager launches measured faster)
+    "angle_feat_dim": 256,   # feat_dim of AngleModel for the 'angleNet' method (the reference hard-codes 256, experiment.py:83)
     "dtype": "f32",          # feature precision of the training step.  'f32' is the reference's arithmetic and the only one the
                              # step implements; 'bf16' exists for the plain SpMM only (LPBatch.spmm_bf16 / mllp_spmm_csr_bf16)
 }

@@ -142,10 +142,19 @@ def get_netlib_dataset(normalize=True, names: Optional[Sequence[str]] = None):
     return dataset, train_dict
 
 
-def get_netlib_dataset_dense(normalize=True):
-    # reference linear_program_data.py:22-55 feeds AngleModel/InvariantModel only
-    raise NotImplementedError("get_netlib_dataset_dense feeds the dense 'angleNet'/'invariant' methods, "
-                              "which are outside the sparse bipartite hot path this build implements")
+def get_netlib_dataset_dense(normalize=True, names: Optional[Sequence[str]] = None):
+    """Drop-in for reference linear_program_data.py:22-55 (the `angleNet` method): ONE instance -- the reference stops
+    after the first entry of `os.listdir`, whose order is arbitrary; here the first instance of the (sorted, or named)
+    dataset -- as (name, Q of [A | b]^T, coefs with a 0 appended, basis)."""
+    from .angle import dense_instance_tensors
+    dataset, train_dict = [], {"obj": []}
+    for inst in load_instances(names, normalize)[:1]:
+        Q, coefs, basis = dense_instance_tensors(inst)
+        print("Instance {} size: {}".format(1, (inst.m, inst.n)))
+        print(Q.shape)
+        dataset.append((inst.name, Q, coefs, basis))
+        train_dict[inst.name] = []
+    return dataset, train_dict
 
 
 # ----------------------------------------------------------------------------------------------

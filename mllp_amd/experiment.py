@@ -168,22 +168,70 @@ def load_checkpoint(path, trainer, train_dict, device):
     return int(ck["epoch"]) + 1
 
 
+def train_angle(cfg, method_name, train_dataset, train_dict, out=print):
+    """reference linear_program_experiment.py:81-114: AngleModel(feat_dim=256) on the complete angle graph of the
+    dense dataset's instance, BCEWithLogits + Adam, top-k metrics, train_log.json, state_dict .pt."""
+    from .angle import AngleModel, get_netlib_dataloader
+    out(f"Training the model weights for {method_name}...")
+    device = torch.device(cfg.get_default("device"))
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("this build runs the learned-LP path on MI355X through HIP only (device: 'cuda'); "
+                           "there is no CPU fallback")
+    train_loader = get_netlib_dataloader(train_dataset, device)                     # reference :33
+    model = AngleModel(feat_dim=int(cfg.get_default("angle_feat_dim"))).to(device)  # reference :83
+    criterion = torch.nn.BCEWithLogitsLoss()                                        # reference :41
+    train_optimizer = torch.optim.Adam(model.parameters(), lr=cfg.train_lr)         # reference :87
+    for epoch in range(cfg.train_iter):
+        obj_sum = 0.0
+        for graph in train_loader:
+            name, basis_num, var_num = graph.name, graph.basis_num, graph.var_num
+            basis_opt = torch.tensor(np.asarray(graph.basis_opt), dtype=torch.float, device=device)
+            train_optimizer.zero_grad()
+            latent_vars = model(graph)
+            obj = criterion(latent_vars, basis_opt)
+            obj.backward()
+            obj_sum += float(obj.detach())
+            train_optimizer.step()
+            pred_indices = torch.topk(latent_vars, k=basis_num)[-1].cpu().detach().numpy()
+            pred = np.zeros(var_num)
+            pred[pred_indices] = 1
+            truth = basis_opt.cpu().numpy()
+            correct_num = float(pred @ truth)
+            tp = correct_num
+            f1 = 2.0 * tp / max(pred.sum() + truth.sum(), 1.0)                      # sklearn f1_score on {0,1} vectors
+            out("%8d, %8d, %8d, %5f" % (correct_num, basis_num, var_num, f1))
+            train_dict[name].append(correct_num)
+        train_dict["obj"].append(obj_sum / len(train_dataset))
+        with open("train_log.json", "w") as json_file:
+            json.dump(train_dict, json_file)
+        out(f"epoch {epoch}, obj={obj_sum / len(train_dataset)}")
+    model_path = f"linear_program_{cfg.train_data_type}_{method_name}.pt"
+    torch.save(model.state_dict(), model_path)                                      # reference :176
+    out(f"Model saved to {model_path}.")
+    return train_dict
+
+
 def main(argv=None):
     cfg = load_config(argv)                                                         # reference :17
     set_seed()                                                                      # reference :19
     if cfg.train_data_type == "netlib":                                             # reference :28-35
         names = cfg.get_default("instances")
-        if cfg.methods[0] in ("invariant", "angleNet"):
+        if cfg.methods[0] == "invariant":
             raise NotImplementedError(
-                f"method {cfg.methods[0]!r} is the reference's dense research path (AngleModel / InvariantModel, "
-                "reference linear_program_methods.py:136-200); this build implements the sparse bipartite "
-                f"GNNModel path: use one of {SPARSE_METHODS}")
-        train_dataset, train_dict = get_netlib_dataset(normalize=True, names=names)
+                "method 'invariant' is the reference's InvariantModel research path (reference "
+                f"linear_program_methods.py:136-185), not built: use 'angleNet' or one of {SPARSE_METHODS}")
+        if cfg.methods[0] == "angleNet":                                            # reference :31-33
+            from .data import get_netlib_dataset_dense
+            train_dataset, train_dict = get_netlib_dataset_dense(normalize=True, names=names)
+        else:
+            train_dataset, train_dict = get_netlib_dataset(normalize=True, names=names)
     else:
         raise ValueError(f"Unknown training dataset {cfg.train_data_type}!")
     for method_name in cfg.methods:                                                 # reference :45
         if method_name in SPARSE_METHODS:
             train_method(cfg, method_name, train_dataset, train_dict)
+        elif method_name == "angleNet":
+            train_angle(cfg, method_name, train_dataset, train_dict)
         else:
             raise NotImplementedError(f"method {method_name!r} is outside the sparse bipartite hot path of this "
                                       f"build (supported: {SPARSE_METHODS})")

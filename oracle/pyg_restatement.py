@@ -139,8 +139,8 @@ def segment_softmax(src, index, num_nodes):
 
 def transformer_conv(sd, prefix, x_src, x_dst, edge_index, edge_attr):
     """edge_index[0] = source j, edge_index[1] = target i (flow source_to_target, aggr add)."""
-    C = FEAT
     W = lambda name: sd[f"{prefix}.{name}"]
+    C = W("lin_query.weight").shape[0]      # out_channels (FEAT = 16 in GNNModel, feat_dim in AngleModel)
     query = x_dst @ W("lin_query.weight").T + W("lin_query.bias")
     key = x_src @ W("lin_key.weight").T + W("lin_key.bias")
     value = x_src @ W("lin_value.weight").T + W("lin_value.bias")

@@ -50,8 +50,11 @@ def test_loader_contract(tmp_path, monkeypatch):
     assert len(constrs) == 27 == len(rhs) and len(coefs) == 51 == len(basis) and len(w) == 102
     assert constrs[0].dtype == np.int32 and w.dtype == np.float64 and basis.dtype == np.int32
     assert set(np.unique(basis)) <= {0, 1}
-    with pytest.raises(NotImplementedError):
-        datamod.get_netlib_dataset_dense()
+    dense, tdict = datamod.get_netlib_dataset_dense(names=["afiro"])       # ONE instance, Q of [A | b]^T
+    assert len(dense) == 1 and list(tdict) == ["obj", "afiro.mps"]
+    nm, Q, cf, bs = dense[0]
+    assert nm == "afiro.mps" and Q.shape == (52, 27) and cf.shape == (52,) and cf[-1] == 0.0 and bs.shape == (51,)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(27), atol=1e-12)
 
 
 def test_loader_reads_reference_layout_when_present(tmp_path, monkeypatch):
@@ -288,13 +291,14 @@ def test_root_shims_and_driver_argument_errors(tmp_path, monkeypatch):
     from mllp_amd import experiment
     assert root_config.load_config is cfgmod.load_config and root_data.get_netlib_dataset is datamod.get_netlib_dataset
     assert root_methods.GNNModel.__name__ == "GNNModel"
+    assert root_methods.AngleModel.__name__ == "AngleModel" and callable(root_methods.build_graph_from_Q_sets)
     with pytest.raises(NotImplementedError):
-        root_methods.AngleModel
+        root_methods.InvariantModel
     with pytest.raises(ValueError, match="Please specify path to the configuration file!"):
         experiment.main([])
     y = tmp_path / "angle.yaml"
-    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'angleNet'\n")
-    with pytest.raises(NotImplementedError, match="angleNet"):
+    y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\nmethods:\n  - 'invariant'\n")
+    with pytest.raises(NotImplementedError, match="invariant"):
         experiment.main(["--cfg", str(y)])
     y.write_text("train_data_type: 'netlib'\ntrain_lr: 1.e-3\ntrain_iter: 1\ndtype: bf16\nmethods:\n  - 'gs-topk'\n")
     with pytest.raises(NotImplementedError, match="bf16"):       # stated, not silently computed in fp32

@@ -9,11 +9,11 @@
 //     L_ij = (Q_i . K_j + (Q_i . we) A_ij) / sqrt(F)      for j != i           (key_j + lin_edge(a_ij), target i, source j)
 //     alpha = softmax_j(L)   (torch_geometric.utils.softmax: exp(L - max) / (sum + 1e-16))
 //     O_i  = sum_j alpha_ij V_j + (sum_j alpha_ij A_ij) we + R_i ,   H = relu(O)
-// so the hot operations are N x N x F GEMMs (rocBLAS sgemm: plain library GEMMs, exact fp32 on the MFMA) and the fused
+// so the hot operations are N x N x F GEMMs (rocBLAS sgemm, loaded on first use: plain library GEMMs, exact fp32) and the fused
 // row kernels below (bias / row dot, masked softmax with the edge term, softmax backward with the edge reductions).
 // A [N, N] is the dense cosine matrix (diagonal ignored: the graph has no self loops).  The backward pass is hand-derived
 // (tests/test_angle.py checks it against fp64 autograd of the oracle's literal TransformerConv on the edge list).
-#include <rocblas/rocblas.h>
+#include <dlfcn.h>
 
 #include <cmath>
 
@@ -25,29 +25,47 @@ namespace {
 
 constexpr int AT = 256;     // threads of the row kernels
 
-rocblas_handle angle_handle() {
-    static rocblas_handle h = [] {
-        rocblas_handle x = nullptr;
-        if (rocblas_create_handle(&x) != rocblas_status_success) return (rocblas_handle) nullptr;
-        rocblas_set_atomics_mode(x, rocblas_atomics_not_allowed);      // deterministic sums (no split-K atomics)
+// rocBLAS is loaded on first use (dlopen): the sparse hot path of this library neither links nor loads it.  The four
+// entry points and the enum values below are rocBLAS' public C API (rocblas/internal/rocblas-types.h).
+struct Blas {
+    void* handle = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*sgemm)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*,
+                 int) = nullptr;
+};
+constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112, ROCBLAS_ATOMICS_NOT_ALLOWED = 0;
+
+const Blas& blas() {
+    static Blas b = [] {
+        Blas x;
+        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return x;
+        auto create = reinterpret_cast<int (*)(void**)>(dlsym(lib, "rocblas_create_handle"));
+        auto atomics = reinterpret_cast<int (*)(void*, int)>(dlsym(lib, "rocblas_set_atomics_mode"));
+        x.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(lib, "rocblas_set_stream"));
+        x.sgemm = reinterpret_cast<decltype(x.sgemm)>(dlsym(lib, "rocblas_sgemm"));
+        if (!create || !atomics || !x.set_stream || !x.sgemm || create(&x.handle) != 0) {
+            x.handle = nullptr;
+            return x;
+        }
+        atomics(x.handle, ROCBLAS_ATOMICS_NOT_ALLOWED);      // deterministic sums (no split-K atomics)
         return x;
     }();
-    return h;
+    return b;
 }
 
 // row-major C[M, N] = alpha * op(A) * op(B) + beta * C   (op(A): M x K, op(B): K x N)
 int gemm_rm(hipStream_t s, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
             const float* B, int64_t ldb, float beta, float* C, int64_t ldc) {
     if (M == 0 || N == 0) return MLLP_OK;
-    rocblas_handle h = angle_handle();
-    if (!h) return fail(MLLP_EHIP, "rocblas_create_handle failed");
-    rocblas_set_stream(h, s);
+    const Blas& b = blas();
+    if (!b.handle) return fail(MLLP_EHIP, "rocBLAS (librocblas.so) could not be loaded: AngleModel needs it for its dense GEMMs");
+    b.set_stream(b.handle, s);
     // a row-major matrix is its transpose in column-major storage: C^T = op(B)^T op(A)^T
-    const rocblas_status st =
-        rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
-                      ta ? rocblas_operation_transpose : rocblas_operation_none, (rocblas_int)N, (rocblas_int)M,
-                      (rocblas_int)K, &alpha, B, (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc);
-    return st == rocblas_status_success ? MLLP_OK : fail(MLLP_EHIP, "rocblas_sgemm failed");
+    const int st = b.sgemm(b.handle, tb ? ROCBLAS_OP_T : ROCBLAS_OP_N, ta ? ROCBLAS_OP_T : ROCBLAS_OP_N, (int)N, (int)M, (int)K,
+                           &alpha, B, (int)ldb, A, (int)lda, &beta, C, (int)ldc);
+    return st == 0 ? MLLP_OK : fail(MLLP_EHIP, "rocblas_sgemm failed");
 }
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {

@@ -387,11 +387,12 @@ __device__ __forceinline__ void gather4_issue(const ItemsDev& s, const float* __
     const float am = __int_as_float(en.y);
     const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm), c2 = quad_bcast_i<2>(colm), c3 = quad_bcast_i<3>(colm);
     g.a0 = quad_bcast<0>(am); g.a1 = quad_bcast<1>(am); g.a2 = quad_bcast<2>(am); g.a3 = quad_bcast<3>(am);
-    g.x0 = f4zero(); g.x1 = f4zero(); g.x2 = f4zero(); g.x3 = f4zero();
-    if (k0 < n_mine) g.x0 = ld4(X + (size_t)c0 * 16 + 4 * part);
-    if (k0 + 1 < n_mine) g.x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
-    if (k0 + 2 < n_mine) g.x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
-    if (k0 + 3 < n_mine) g.x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
+    // unconditional: a slot past the row's end carries the entry {0, 0} and gathers row 0, which the steps mask out
+    // (sixteen zeroing moves and four exec-masked branches less per step than loads under `if (k < n_mine)`)
+    g.x0 = ld4(X + (size_t)c0 * 16 + 4 * part);
+    g.x1 = ld4(X + (size_t)c1 * 16 + 4 * part);
+    g.x2 = ld4(X + (size_t)c2 * 16 + 4 * part);
+    g.x3 = ld4(X + (size_t)c3 * 16 + 4 * part);
     const int kn = k0 + 4 + part;
     en = kn < n_mine ? s.sent[r.first + kn * r.stride] : make_int2(0, 0);
 }
@@ -1213,30 +1214,6 @@ struct SrcLaunch16 {
 };
 
 // two gathered destination records of a quad
-struct GatherRec2 {
-    float4 q0, g0, s0, q1, g1, s1;
-    float a0, a1, cc0, cc1;
-};
-__device__ __forceinline__ void rec2_issue(const SrcJob16& J, const RowSlot& r, int n_mine, int k0, int part, int2& en,
-                                           GatherRec2& g) {
-    const int colm = en.x;
-    const float am = __int_as_float(en.y);
-    const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm);
-    g.a0 = quad_bcast<0>(am); g.a1 = quad_bcast<1>(am);
-    g.q0 = f4zero(); g.g0 = f4zero(); g.s0 = f4zero(); g.q1 = f4zero(); g.g1 = f4zero(); g.s1 = f4zero();
-    g.cc0 = 0.0f; g.cc1 = 0.0f;
-    if (k0 < n_mine) {
-        const float* rr = J.rec + (size_t)c0 * REC_W;
-        g.q0 = ld4(rr + 4 * part); g.g0 = ld4(rr + 16 + 4 * part); g.s0 = ld4(rr + 32); g.cc0 = rr[36];
-    }
-    if (k0 + 1 < n_mine) {
-        const float* rr = J.rec + (size_t)c1 * REC_W;
-        g.q1 = ld4(rr + 4 * part); g.g1 = ld4(rr + 16 + 4 * part); g.s1 = ld4(rr + 32); g.cc1 = rr[36];
-    }
-    const int kn = k0 + 2 + (part & 1);
-    en = kn < n_mine ? J.s.sent[r.first + kn * r.stride] : make_int2(0, 0);
-}
-
 __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, float4& xj_io, int2& en, const SlotReq& qn,
                                           RowSlot& rn, int part, int lane, float* merge_lds) {
     const int n_mine = slot_count(r);
@@ -1249,16 +1226,13 @@ __device__ __forceinline__ void src16_row(const SrcJob16& J, const RowSlot& r, f
         const int c0 = quad_bcast_i<0>(colm), c1 = quad_bcast_i<1>(colm);
         const float a0 = quad_bcast<0>(am), a1 = quad_bcast<1>(am);
         const bool ok0 = k0 < n_mine, ok1 = k0 + 1 < n_mine;
-        float4 q0 = f4zero(), g0 = f4zero(), s0 = f4zero(), q1 = f4zero(), g1 = f4zero(), s1 = f4zero();
-        float cc0 = 0.0f, cc1 = 0.0f;
-        if (ok0) {
-            const float* rr = J.rec + (size_t)c0 * REC_W;
-            q0 = ld4(rr + 4 * part); g0 = ld4(rr + 16 + 4 * part); s0 = ld4(rr + 32); cc0 = rr[36];
-        }
-        if (ok1) {
-            const float* rr = J.rec + (size_t)c1 * REC_W;
-            q1 = ld4(rr + 4 * part); g1 = ld4(rr + 16 + 4 * part); s1 = ld4(rr + 32); cc1 = rr[36];
-        }
+        // unconditional (see gather4_issue): a slot past the end reads record 0 and is masked out through `al`
+        const float* rr0 = J.rec + (size_t)c0 * REC_W;
+        const float* rr1 = J.rec + (size_t)c1 * REC_W;
+        const float4 q0 = ld4(rr0 + 4 * part), g0 = ld4(rr0 + 16 + 4 * part), s0 = ld4(rr0 + 32);
+        const float cc0 = rr0[36];
+        const float4 q1 = ld4(rr1 + 4 * part), g1 = ld4(rr1 + 16 + 4 * part), s1 = ld4(rr1 + 32);
+        const float cc1 = rr1[36];
         const int kn = k0 + 2 + (part & 1);
         en = kn < n_mine ? J.s.sent[r.first + kn * r.stride] : make_int2(0, 0);
         {

@@ -16,6 +16,7 @@ for f in files:
         for r in csv.DictReader(fh):
             name = r.get("Kernel_Name") or r.get("kernel_name")
             t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            name = name.replace("(anonymous namespace)::", "")
             name = re.sub(r"\(.*$", "", name)
             name = name.replace("void mllp::", "").replace("mllp::", "")
             s = stat[name]

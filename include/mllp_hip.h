@@ -110,6 +110,23 @@ int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, fl
  * Runs on the LDS-tiled copy only (mllp_graph_attach_tiled, variant 0); MLLP_EINVAL without it.            */
 int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf16, float* d_Y, void* stream);
 
+/* Streamed copy of one orientation for mllp_spmm_csr_f32 on large batches (rows of ~100+ nonzeros; layout and
+ * rationale: mllp_amd/csrc/stream_layout.h).  The nonzeros are re-blocked ONCE into 512-row tiles x 1000-column
+ * blocks and stored in the order the kernel's wavefronts consume them, so that they stream HBM -> registers while LDS
+ * holds two images of H (double-buffered by LDS-DMA).  Replaces the edge list the reference rebuilds every step
+ * (linear_program_methods.py:89-103).  The copy is LIBRARY-owned device memory (these three are not launch functions:
+ * they allocate, free and synchronise), ~8.6 bytes per nonzero; mllp_spmm_csr_f32 uses it when present.
+ *   where: 0 = built on the device (counting + placement kernels), 1 = built by the host reference builder
+ *          (same bytes; tests compare the two).
+ *   mllp_graph_spmm_copy_info: info[0..7] = row tiles, (tile, block) pairs, 1 KB entry groups, entry slots (padding
+ *          included; compare with nnz), bytes of the copy, microseconds the build took, rows per tile, columns per block.
+ *   mllp_graph_export_spmm_copy (tests): which = 0 tile_blk (int32, tiles + 1), 1 blk_id (int32), 2 records
+ *          (int32 x 4 per (tile-block, wavefront, quad)), 3 entry stream (int32 x 4 per (group, lane)).          */
+int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* stream);
+int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose);
+int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]);
+int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which, void* host_dst, int64_t capacity_bytes);
+
 /* Optional LDS-tiled copy of one orientation for large batches (rows of ~100+ nonzeros): the nonzeros
  * re-blocked into row tiles x column blocks so that source rows are read from LDS instead of L2.
  *   mllp_tiled_geometry: rows per tile, source nodes per column block, and the number of entries of one

@@ -219,6 +219,8 @@ extern "C" int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_
 
 extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     if (!g) return MLLP_OK;
+    mllp::stream_copy_free(g->A.stream);
+    mllp::stream_copy_free(g->At.stream);
     for (void* p : g->allocs) (void)hipFree(p);
     for (auto& e : g->ev)
         if (e) (void)hipEventDestroy(e);

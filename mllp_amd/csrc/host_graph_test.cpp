@@ -10,6 +10,8 @@
 
 #include "../../include/mllp_hip.h"
 #include "host_graph.h"
+#include "host_stream.h"
+#include "stream_layout.h"
 
 using namespace mllp;
 
@@ -231,6 +233,76 @@ static void check_mps(const char* path, bool synthetic) {
     }
 }
 
+
+// Streamed SpMM copy (host_stream.cpp): random matrices that span several row tiles and column blocks (empty rows, one
+// row denser than a block's window, a ragged last tile / block); the copy is walked the way the kernel's wavefronts
+// walk it and must reproduce the CSR product, visit every nonzero exactly once, and be identical when built again
+// with another thread count.
+static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_deg, int long_row) {
+    std::vector<int> ptr(1, 0), idx;
+    std::vector<float> val;
+    for (int r = 0; r < n_dst; ++r) {
+        int deg = (int)(mean_deg * 2.0 * (rng() % 1000) / 1000.0);
+        if (rng() % 5 == 0) deg = 0;
+        if (r == 7) deg = long_row;
+        deg = std::min(deg, n_src);
+        std::vector<int> cols;
+        if (deg * 3 > n_src) {
+            std::vector<int> all(n_src);
+            for (int c = 0; c < n_src; ++c) all[c] = c;
+            for (int c = 0; c < deg; ++c) std::swap(all[c], all[c + rng() % (n_src - c)]);
+            cols.assign(all.begin(), all.begin() + deg);
+        } else {
+            while ((int)cols.size() < deg) {
+                const int c = (int)(rng() % n_src);
+                if (std::find(cols.begin(), cols.end(), c) == cols.end()) cols.push_back(c);
+            }
+        }
+        std::sort(cols.begin(), cols.end());
+        for (int c : cols) {
+            idx.push_back(c);
+            val.push_back((float)(int)(rng() % 2001 - 1000) / 1000.0f + 0.0005f);
+        }
+        ptr.push_back((int)idx.size());
+    }
+    std::vector<float> H((size_t)n_src * 16);
+    for (auto& h : H) h = (float)(int)(rng() % 2001 - 1000) / 500.0f;
+    HostStream a, b;
+    std::string err;
+    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, &a, &err, 8) == MLLP_OK);
+    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, &b, &err, 1) == MLLP_OK);
+    CHECK(a.tile_blk == b.tile_blk && a.blk_id == b.blk_id && a.rec == b.rec && a.ent == b.ent && a.n_groups == b.n_groups);
+    CHECK(a.n_tiles == (n_dst + S_R - 1) / S_R && (int)a.tile_blk.size() == a.n_tiles + 1 && a.tile_blk[a.n_tiles] == a.n_tb);
+    CHECK(a.ent.size() == (size_t)(a.n_groups + S_K) * 256 && a.real_slots == (int64_t)idx.size());
+    CHECK(a.step_slots >= a.real_slots);
+    std::vector<double> Y((size_t)n_dst * 16, 0.0), Yref((size_t)n_dst * 16, 0.0);
+    CHECK(host_walk_stream(a, n_dst, n_src, H.data(), Y.data()) == (int64_t)idx.size());
+    for (int r = 0; r < n_dst; ++r)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e)
+            for (int c = 0; c < 16; ++c) Yref[(size_t)r * 16 + c] += (double)val[e] * (double)H[(size_t)idx[e] * 16 + c];
+    for (size_t i = 0; i < Y.size(); ++i) CHECK(std::fabs(Y[i] - Yref[i]) <= 1e-9 * (1.0 + std::fabs(Yref[i])));
+    // records: every row of a tile appears exactly once per (tile, block); steps of a wavefront are contiguous
+    for (int t = 0; t < a.n_tiles; ++t) {
+        std::vector<int64_t> next(S_NW, -1);
+        for (int tb = a.tile_blk[t]; tb < a.tile_blk[t + 1]; ++tb) {
+            CHECK(tb == a.tile_blk[t] || a.blk_id[tb] > a.blk_id[tb - 1]);
+            std::vector<int> seen(S_R, 0);
+            for (int w = 0; w < S_NW; ++w) {
+                const int* rec = &a.rec[(((size_t)tb * S_NW + w) * 16) * 4];
+                if (next[w] >= 0) CHECK(rec[2] == next[w]);
+                else CHECK(rec[2] % 4 == 0);
+                next[w] = (int64_t)rec[2] + (rec[3] & 0xffff) + (int)((unsigned)rec[3] >> 16);
+                for (int q = 0; q < 16; ++q)
+                    for (int k = 0; k < 2; ++k) {
+                        seen[rec[q * 4 + k] & 0xffff]++;
+                        seen[(rec[q * 4 + k] >> 16) & 0xffff]++;
+                    }
+            }
+            for (int r = 0; r < S_R; ++r) CHECK(seen[r] == 1);
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     for (int a = 1; a < argc; ++a) check_mps(argv[a], false);
     {
@@ -285,6 +357,17 @@ int main(int argc, char** argv) {
             check_fused(b.csr_ptr.data(), (int)b.M, b.pm, part);
             check_fused(b.csc_ptr.data(), (int)b.N, b.pn, part);
         }
+    }
+    check_stream(rng, 1300, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 3 column blocks, a 1400-entry row
+    check_stream(rng, 512, 1000, 3.0, 1000);       // exactly one tile, one block, one full row
+    check_stream(rng, 40, 60, 2.0, 5);
+    check_stream(rng, 600, 4100, 40.0, 0);
+    {   // no rows at all
+        HostStream e;
+        std::string err;
+        const int p0[1] = {0};
+        CHECK(host_build_stream(p0, nullptr, nullptr, 0, 10, &e, &err) == MLLP_OK && e.n_tiles == 0 && e.n_groups == 0);
+        CHECK(e.ent.size() == (size_t)S_K * 256);
     }
     {   // empty batch and argument errors
         HostBatch b;

@@ -1,0 +1,33 @@
+// host_stream.h -- host (plain C++) builder of the streamed SpMM copy (stream_layout.h) and a host walk of it.
+// The device builder (stream_spmm.hip) must produce the same bytes; the GPU tests compare the two, and the sanitizer
+// driver (host_graph_test.cpp) checks this one against the CSR it came from by walking the copy exactly as the
+// kernel's wavefronts do.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace mllp {
+
+struct HostStream {
+    int n_tiles = 0, n_tb = 0;
+    int64_t n_groups = 0;            // groups of 4 steps (without the S_K padding groups at the end)
+    int64_t real_slots = 0;          // = nnz
+    int64_t step_slots = 0;          // 128 x groups: entry slots of the stream (padding included)
+    std::vector<int> tile_blk;       // [n_tiles + 1]
+    std::vector<int> blk_id;         // [n_tb]
+    std::vector<int> rec;            // [n_tb * 8 * 16 * 4]
+    std::vector<int> ent;            // [(n_groups + S_K) * 64 * 4]
+};
+
+// 0 on success, an MLLP_E* code with *err set otherwise (sizes beyond int32 steps).  max_threads = 0: hardware
+// concurrency, at most 16.
+int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src, HostStream* out,
+                      std::string* err, unsigned max_threads = 0);
+
+// Y[n_dst,16] (double) += the product, computed by walking the copy the way spmm_stream_kernel does (records, passes,
+// steps, groups); returns the number of real (non-padding) entries visited, -1 on a malformed copy.
+int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y);
+
+}  // namespace mllp

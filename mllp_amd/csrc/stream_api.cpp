@@ -1,0 +1,115 @@
+// stream_api.cpp -- C ABI of the streamed SpMM copy (stream_layout.h): build (device kernels or the host reference
+// builder), info, export, drop.  The copy is library-owned device memory, freed on rebuild / drop / graph destroy.
+#include <chrono>
+#include <vector>
+
+#include "host_stream.h"
+#include "internal.h"
+#include "stream_layout.h"
+
+namespace mllp {
+
+void stream_copy_free(StreamCopy& sc) {
+    if (sc.tile_blk) (void)hipFree(sc.tile_blk);
+    if (sc.blk_id) (void)hipFree(sc.blk_id);
+    if (sc.rec) (void)hipFree(sc.rec);
+    if (sc.ent) (void)hipFree(sc.ent);
+    sc = StreamCopy();
+}
+
+static int build_on_host(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_t s) {
+    std::vector<int> ptr((size_t)o.n_dst + 1, 0), idx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
+    MLLP_HIP_TRY(hipStreamSynchronize(s));
+    if (o.n_dst > 0) MLLP_HIP_TRY(hipMemcpy(ptr.data(), o.ptr, ((size_t)o.n_dst + 1) * 4, hipMemcpyDeviceToHost));
+    if (nnz > 0) {
+        MLLP_HIP_TRY(hipMemcpy(idx.data(), o.idx, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+        MLLP_HIP_TRY(hipMemcpy(val.data(), o.val, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+    }
+    HostStream h;
+    std::string err;
+    const int rc = host_build_stream(ptr.data(), idx.data(), val.data(), o.n_dst, o.n_src, &h, &err);
+    if (rc) return fail(rc, err);
+    sc.n_tiles = h.n_tiles;
+    sc.n_tb = h.n_tb;
+    sc.n_groups = h.n_groups;
+    sc.step_slots = h.step_slots;
+    auto up = [&](int*& d, const std::vector<int>& v) -> int {
+        MLLP_HIP_TRY(hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * 4));
+        if (!v.empty()) MLLP_HIP_TRY(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        return MLLP_OK;
+    };
+    int r;
+    if ((r = up(sc.tile_blk, h.tile_blk)) || (r = up(sc.blk_id, h.blk_id)) || (r = up(sc.rec, h.rec)) ||
+        (r = up(sc.ent, h.ent)))
+        return r;
+    return MLLP_OK;
+}
+
+}  // namespace mllp
+
+using namespace mllp;
+
+#define REQUIRE(cond, msg) \
+    if (!(cond)) return fail(MLLP_EINVAL, std::string(__func__) + ": " + (msg))
+
+extern "C" int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* stream) {
+    REQUIRE(g, "null graph");
+    REQUIRE(where == 0 || where == 1, "where must be 0 (device builder) or 1 (host reference builder)");
+    Orient& o = transpose ? g->At : g->A;
+    stream_copy_free(o.stream);
+    if (o.n_dst == 0) return MLLP_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    StreamCopy sc;
+    const int rc = where == 1 ? build_on_host(o, g->nnz, sc, (hipStream_t)stream)
+                              : build_stream_device(o, g->nnz, sc, (hipStream_t)stream);
+    if (rc) {
+        stream_copy_free(sc);
+        return rc;
+    }
+    sc.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    o.stream = sc;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose) {
+    REQUIRE(g, "null graph");
+    stream_copy_free((transpose ? g->At : g->A).stream);
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]) {
+    REQUIRE(g && info, "null argument");
+    const StreamCopy& sc = (transpose ? g->At : g->A).stream;
+    info[0] = sc.n_tiles;
+    info[1] = sc.n_tb;
+    info[2] = sc.n_groups;
+    info[3] = sc.step_slots;
+    info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 4 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * S_NW * 256 +
+                               (sc.n_groups + S_K) * 1024
+                         : 0;                                   // bytes of the copy
+    info[5] = (int64_t)(sc.build_seconds * 1e6);                // microseconds the build took (host clock, synchronised)
+    info[6] = S_R;
+    info[7] = S_CB;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which, void* host_dst,
+                                           int64_t capacity_bytes) {
+    REQUIRE(g && host_dst, "null argument");
+    const StreamCopy& sc = (transpose ? g->At : g->A).stream;
+    REQUIRE(sc.n_tiles > 0, "no streamed copy of this orientation (mllp_graph_build_spmm_copy)");
+    const void* src = nullptr;
+    int64_t bytes = 0;
+    switch (which) {
+        case 0: src = sc.tile_blk; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
+        case 1: src = sc.blk_id; bytes = (int64_t)sc.n_tb * 4; break;
+        case 2: src = sc.rec; bytes = (int64_t)sc.n_tb * S_NW * 256; break;
+        case 3: src = sc.ent; bytes = (sc.n_groups + S_K) * 1024; break;
+        default: return fail(MLLP_EINVAL, "mllp_graph_export_spmm_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rec) or 3 (ent)");
+    }
+    REQUIRE(capacity_bytes >= bytes, "destination too small");
+    MLLP_HIP_TRY(hipDeviceSynchronize());
+    if (bytes > 0) MLLP_HIP_TRY(hipMemcpy(host_dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return MLLP_OK;
+}

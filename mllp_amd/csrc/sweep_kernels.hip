@@ -691,6 +691,7 @@ static int launch_sweep(const Orient& o, const typename Op::Args& args, float* s
 }
 
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s) {
+    if (o.stream.n_tiles > 0) return launch_spmm_stream(o.stream, o.n_dst, o.n_src, H, Y, s);
     if (o.tiled.n_tiles > 0) return launch_spmm_tiled(o.tiled, o.n_dst, o.n_src, H, Y, s);
     SpmmOp::Args a{H, Y};
     return launch_sweep<SpmmOp, 4, 4>(o, a, scratch, s, "spmm_csr");

@@ -283,6 +283,35 @@ class LPBatch:
         self._tiled[(bool(transpose), int(variant))] = keep          # the library borrows these arrays
         return info
 
+    # ---- streamed SpMM copy (library-owned; stream_layout.h) -----------------------------------------
+    def build_spmm_copy(self, transpose=False, where="device"):
+        """Build the streamed copy of A (or A^T) that `spmm` then runs on: `where` = "device" (HIP builder) or
+        "host" (reference builder, same bytes).  Returns the info dict of `spmm_copy_info`."""
+        _lib.check(_lib.lib().mllp_graph_build_spmm_copy(self._h, int(transpose), {"device": 0, "host": 1}[where],
+                                                         _lib.current_stream()))
+        return self.spmm_copy_info(transpose)
+
+    def drop_spmm_copy(self, transpose=False):
+        _lib.check(_lib.lib().mllp_graph_drop_spmm_copy(self._h, int(transpose)))
+
+    def spmm_copy_info(self, transpose=False):
+        d = (c_int64 * 8)()
+        _lib.check(_lib.lib().mllp_graph_spmm_copy_info(self._h, int(transpose), d))
+        keys = ["n_tiles", "n_tb", "n_groups", "entry_slots", "bytes", "build_us", "rows_per_tile", "cols_per_block"]
+        return dict(zip(keys, [int(v) for v in d]))
+
+    def export_spmm_copy(self, transpose=False):
+        """(tile_blk, blk_id, rec [n_tb, 8, 16, 4], ent [groups + 8, 64, 4]) as numpy int32 arrays (tests)."""
+        i = self.spmm_copy_info(transpose)
+        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], 8, 16, 4), (i["n_groups"] + 8, 64, 4)]
+        out = []
+        for which, shp in enumerate(shapes):
+            a = np.empty(shp, dtype=np.int32)
+            _lib.check(_lib.lib().mllp_graph_export_spmm_copy(self._h, int(transpose), which,
+                                                              a.ctypes.data_as(c_void_p), a.nbytes))
+            out.append(a)
+        return tuple(out)
+
     def enable_tiled_all(self):
         """Attach every LDS-tiled copy (variants 0-4, both orientations): the throughput configuration for batches of
         hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""

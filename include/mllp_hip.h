@@ -111,8 +111,8 @@ int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, fl
 int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf16, float* d_Y, void* stream);
 
 /* Streamed copy of one orientation for mllp_spmm_csr_f32 on large batches (rows of ~100+ nonzeros; layout and
- * rationale: mllp_amd/csrc/stream_layout.h).  The nonzeros are re-blocked ONCE into 512-row tiles x 1000-column
- * blocks and stored in the order the kernel's wavefronts consume them, so that they stream HBM -> registers while LDS
+ * rationale: mllp_amd/csrc/stream_layout.h).  The nonzeros are re-blocked ONCE into row tiles of at most 1024 rows (never
+ * across two LP instances) x 625-column blocks and stored in the order the kernel's wavefronts consume them, so that they stream HBM -> registers while LDS
  * holds two images of H (double-buffered by LDS-DMA).  Replaces the edge list the reference rebuilds every step
  * (linear_program_methods.py:89-103).  The copy is LIBRARY-owned device memory (these three are not launch functions:
  * they allocate, free and synchronise), ~8.6 bytes per nonzero; mllp_spmm_csr_f32 uses it when present.
@@ -120,8 +120,9 @@ int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf1
  *          (same bytes; tests compare the two).
  *   mllp_graph_spmm_copy_info: info[0..7] = row tiles, (tile, block) pairs, 1 KB entry groups, entry slots (padding
  *          included; compare with nnz), bytes of the copy, microseconds the build took, rows per tile, columns per block.
- *   mllp_graph_export_spmm_copy (tests): which = 0 tile_blk (int32, tiles + 1), 1 blk_id (int32), 2 records
- *          (int32 x 4 per (tile-block, wavefront, quad)), 3 entry stream (int32 x 4 per (group, lane)).          */
+ *   mllp_graph_export_spmm_copy (tests): which = 0 tile_blk (int32, tiles + 1), 1 blk_id (int32), 2 row records
+ *          (int32 x 4 per (tile-block, wavefront, quad)), 3 entry stream (int32 x 4 per (group, lane)), 4 tile_row
+ *          (int32, tiles + 1), 5 headers (int32 x 4 per (tile-block, wavefront)).                                 */
 int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* stream);
 int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose);
 int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]);

@@ -238,7 +238,7 @@ static void check_mps(const char* path, bool synthetic) {
 // row denser than a block's window, a ragged last tile / block); the copy is walked the way the kernel's wavefronts
 // walk it and must reproduce the CSR product, visit every nonzero exactly once, and be identical when built again
 // with another thread count.
-static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_deg, int long_row) {
+static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_deg, int long_row, int n_seg = 1) {
     std::vector<int> ptr(1, 0), idx;
     std::vector<float> val;
     for (int r = 0; r < n_dst; ++r) {
@@ -269,10 +269,20 @@ static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_de
     for (auto& h : H) h = (float)(int)(rng() % 2001 - 1000) / 500.0f;
     HostStream a, b;
     std::string err;
-    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, &a, &err, 8) == MLLP_OK);
-    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, &b, &err, 1) == MLLP_OK);
-    CHECK(a.tile_blk == b.tile_blk && a.blk_id == b.blk_id && a.rec == b.rec && a.ent == b.ent && a.n_groups == b.n_groups);
-    CHECK(a.n_tiles == (n_dst + S_R - 1) / S_R && (int)a.tile_blk.size() == a.n_tiles + 1 && a.tile_blk[a.n_tiles] == a.n_tb);
+    std::vector<int64_t> seg(1, 0);
+    for (int k = 1; k < n_seg; ++k) seg.push_back((int64_t)n_dst * k / n_seg + (k & 1));
+    seg.push_back(n_dst);
+    const int64_t* sp = n_seg > 1 ? seg.data() : nullptr;
+    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, sp, n_seg, &a, &err, 8) == MLLP_OK);
+    CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, sp, n_seg, &b, &err, 1) == MLLP_OK);
+    CHECK(a.tile_blk == b.tile_blk && a.blk_id == b.blk_id && a.rows == b.rows && a.hdr == b.hdr && a.ent == b.ent &&
+          a.n_groups == b.n_groups && a.tile_row == b.tile_row);
+    CHECK((int)a.tile_row.size() == a.n_tiles + 1 && a.tile_row[0] == 0 && a.tile_row[a.n_tiles] == n_dst);
+    for (int t = 0; t < a.n_tiles; ++t) {
+        CHECK(a.tile_row[t + 1] > a.tile_row[t] && a.tile_row[t + 1] - a.tile_row[t] <= S_R);
+        for (int64_t sgm : seg) CHECK(!(sgm > a.tile_row[t] && sgm < a.tile_row[t + 1]));      // no tile crosses a segment
+    }
+    CHECK((int)a.tile_blk.size() == a.n_tiles + 1 && a.tile_blk[a.n_tiles] == a.n_tb);
     CHECK(a.ent.size() == (size_t)(a.n_groups + S_K) * 256 && a.real_slots == (int64_t)idx.size());
     CHECK(a.step_slots >= a.real_slots);
     std::vector<double> Y((size_t)n_dst * 16, 0.0), Yref((size_t)n_dst * 16, 0.0);
@@ -288,14 +298,16 @@ static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_de
             CHECK(tb == a.tile_blk[t] || a.blk_id[tb] > a.blk_id[tb - 1]);
             std::vector<int> seen(S_R, 0);
             for (int w = 0; w < S_NW; ++w) {
-                const int* rec = &a.rec[(((size_t)tb * S_NW + w) * 16) * 4];
-                if (next[w] >= 0) CHECK(rec[2] == next[w]);
-                else CHECK(rec[2] % 4 == 0);
-                next[w] = (int64_t)rec[2] + (rec[3] & 0xffff) + (int)((unsigned)rec[3] >> 16);
+                const int* hdr = &a.hdr[((size_t)tb * S_NW + w) * 4];
+                const int* rows = &a.rows[(((size_t)tb * S_NW + w) * 16) * 4];
+                if (next[w] >= 0) CHECK(hdr[0] == next[w]);
+                else CHECK(hdr[0] % 2 == 0);
+                CHECK(hdr[2] == a.blk_id[tb] && hdr[3] == 0);
+                next[w] = (int64_t)hdr[0] + (hdr[1] & 0xffff) + (int)((unsigned)hdr[1] >> 16);
                 for (int q = 0; q < 16; ++q)
-                    for (int k = 0; k < 2; ++k) {
-                        seen[rec[q * 4 + k] & 0xffff]++;
-                        seen[(rec[q * 4 + k] >> 16) & 0xffff]++;
+                    for (int k = 0; k < 4; ++k) {
+                        seen[rows[q * 4 + k] & 0xffff]++;
+                        seen[(rows[q * 4 + k] >> 16) & 0xffff]++;
                     }
             }
             for (int r = 0; r < S_R; ++r) CHECK(seen[r] == 1);
@@ -358,15 +370,16 @@ int main(int argc, char** argv) {
             check_fused(b.csc_ptr.data(), (int)b.N, b.pn, part);
         }
     }
-    check_stream(rng, 1300, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 3 column blocks, a 1400-entry row
-    check_stream(rng, 512, 1000, 3.0, 1000);       // exactly one tile, one block, one full row
+    check_stream(rng, 2600, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 4 column blocks, a 1400-entry row
+    check_stream(rng, S_R, S_CB, 3.0, S_CB);       // exactly one tile, one block, one full row
     check_stream(rng, 40, 60, 2.0, 5);
-    check_stream(rng, 600, 4100, 40.0, 0);
+    check_stream(rng, 1200, 4100, 40.0, 0);
+    check_stream(rng, 3000, 1500, 9.0, 30, 4);     // four segments: ragged tiles at every segment end
     {   // no rows at all
         HostStream e;
         std::string err;
         const int p0[1] = {0};
-        CHECK(host_build_stream(p0, nullptr, nullptr, 0, 10, &e, &err) == MLLP_OK && e.n_tiles == 0 && e.n_groups == 0);
+        CHECK(host_build_stream(p0, nullptr, nullptr, 0, 10, nullptr, 0, &e, &err) == MLLP_OK && e.n_tiles == 0 && e.n_groups == 0);
         CHECK(e.ent.size() == (size_t)S_K * 256);
     }
     {   // empty batch and argument errors

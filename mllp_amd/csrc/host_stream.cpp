@@ -24,9 +24,9 @@ struct TileScan {
     std::vector<int> order;      // [nb * S_R] sorted position -> row (entries descending, ties by row)
 };
 
-void scan_tile(const int* ptr, const int* idx, int64_t n_dst, int t, TileScan& s) {
-    const int64_t r0 = (int64_t)t * S_R;
-    const int rows = (int)std::min<int64_t>(S_R, n_dst - r0);
+void scan_tile(const int* ptr, const int* idx, const std::vector<int>& tile_row, int t, TileScan& s) {
+    const int64_t r0 = tile_row[t];
+    const int rows = tile_row[t + 1] - tile_row[t];
     s.blocks.clear();
     for (int r = 0; r < rows; ++r) {
         int last = -1;
@@ -57,8 +57,8 @@ void scan_tile(const int* ptr, const int* idx, int64_t n_dst, int t, TileScan& s
     }
 }
 
-inline int pass_steps(const TileScan& s, size_t bi, int pair) {     // entries of the pair's longest row
-    return s.cnt[bi * S_R + s.order[bi * S_R + 32 * pair]];
+inline int pass_steps(const TileScan& s, size_t bi, int bundle) {     // entries of the bundle's longest row
+    return s.cnt[bi * S_R + s.order[bi * S_R + 64 * bundle]];
 }
 
 // one row of a team during the joint ordering
@@ -68,12 +68,12 @@ struct RowCur {
     int nxt[4] = {0, 0, 0, 0};    // scan position per class (relative to beg)
 };
 
-// Entries of the 16 rows `rows[q]` (one per quad) of a pass, written as the A (half = 0) or B (half = 1) entries of
-// steps S .. S + n - 1.  The four rows of a team are ordered JOINTLY: at step p the row that chooses first rotates
+// Entries of the 16 rows `rows[q]` (one per quad) of a pass, written as the entries of row slot `slot` of steps
+// S .. S + n - 1.  The four rows of a team are ordered JOINTLY: at step p the row that chooses first rotates
 // with p; a row takes its most numerous remaining class (column mod 4; lowest class on ties) that no team mate has
 // taken in this step, or its most numerous class when all are taken.  Rows shorter than n keep the padding entries.
-void fill_half(const int* idx, const float* val, int blk, const TileScan& s, size_t bi, const int* rows, int64_t S,
-               int half, int* ent) {
+void fill_slot(const int* idx, const float* val, int blk, const TileScan& s, size_t bi, const int* rows, int64_t S,
+               int slot, int* ent) {
     for (int tm = 0; tm < 4; ++tm) {
         RowCur rc[4];
         int maxlen = 0;
@@ -105,9 +105,9 @@ void fill_half(const int* idx, const float* val, int blk, const TileScan& s, siz
                 used |= 1u << pick;
                 const int64_t step = S + p;
                 const int q = S_TEAMS[tm][i];
-                int* slot = ent + (((step >> 2) * 64 + q * 4 + (step & 3)) * 4 + half * 2);
-                slot[0] = (idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
-                std::memcpy(&slot[1], &val[c.beg + e], 4);
+                int* dst = ent + (((step >> 1) * 64 + q * 4 + slot) * 4 + (step & 1) * 2);
+                dst[0] = (idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
+                std::memcpy(&dst[1], &val[c.beg + e], 4);
             }
         }
     }
@@ -129,19 +129,30 @@ void parallel_tiles(int n_tiles, unsigned nt, F f) {
 
 }  // namespace
 
-int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src, HostStream* out,
-                      std::string* err, unsigned max_threads) {
+std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst) {
+    std::vector<int> tr(1, 0);
+    const int64_t one[2] = {0, n_dst};
+    if (!seg_ptr) { seg_ptr = one; n_seg = 1; }
+    for (int64_t k = 0; k < n_seg; ++k)
+        for (int64_t r = seg_ptr[k]; r < seg_ptr[k + 1]; r += S_R) tr.push_back((int)std::min<int64_t>(r + S_R, seg_ptr[k + 1]));
+    return tr;
+}
+
+int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
+                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads) {
     auto bad = [&](int code, const char* msg) {
         if (err) *err = msg;
         return code;
     };
     if (n_dst < 0 || n_src < 0 || (n_dst > 0 && !ptr)) return bad(MLLP_EINVAL, "host_build_stream: bad arguments");
-    const int64_t n_tiles64 = (n_dst + S_R - 1) / S_R;
-    if (n_tiles64 >= (1 << 28)) return bad(MLLP_ERANGE, "host_build_stream: too many row tiles");
-    const int n_tiles = (int)n_tiles64;
-    const unsigned nt = max_threads ? max_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (seg_ptr && (n_seg < 1 || seg_ptr[0] != 0 || seg_ptr[n_seg] != n_dst))
+        return bad(MLLP_EINVAL, "host_build_stream: segments must cover the rows");
+    if (n_dst >= ((int64_t)1 << 31) - 1) return bad(MLLP_ERANGE, "host_build_stream: too many rows");
     HostStream& o = *out;
     o = HostStream();
+    o.tile_row = host_stream_tiles(seg_ptr, n_seg, n_dst);
+    const int n_tiles = (int)o.tile_row.size() - 1;
+    const unsigned nt = max_threads ? max_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     o.n_tiles = n_tiles;
     o.tile_blk.assign(n_tiles + 1, 0);
 
@@ -150,11 +161,11 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     std::vector<TileScan> scans(nt);
     parallel_tiles(n_tiles, nt, [&](int t, unsigned k) {
         TileScan& s = scans[k];
-        scan_tile(ptr, idx, n_dst, t, s);
+        scan_tile(ptr, idx, o.tile_row, t, s);
         o.tile_blk[t + 1] = (int)s.blocks.size();
         for (size_t bi = 0; bi < s.blocks.size(); ++bi)
             for (int w = 0; w < S_NW; ++w)
-                steps[(size_t)t * S_NW + w] += pass_steps(s, bi, w) + pass_steps(s, bi, S_PAIRS - 1 - w);
+                for (int j = 0; j < S_P; ++j) steps[(size_t)t * S_NW + w] += pass_steps(s, bi, s_bundle(w, j));
     });
     int64_t n_tb = 0;
     for (int t = 0; t < n_tiles; ++t) {
@@ -167,13 +178,14 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     o.n_tb = (int)n_tb;
     std::vector<int64_t> base((size_t)n_tiles * S_NW + 1, 0);     // first group of every (tile, wavefront)
     for (size_t i = 0; i < steps.size(); ++i) {
-        base[i + 1] = base[i] + (steps[i] + 3) / 4;
+        base[i + 1] = base[i] + (steps[i] + 1) / 2;
     }
     o.n_groups = base[steps.size()];
     o.step_slots = o.n_groups * 128;
-    if (o.n_groups * 4 >= ((int64_t)1 << 31) - 4 * S_K) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
+    if (o.n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
     o.blk_id.assign(n_tb, 0);
-    o.rec.assign((size_t)n_tb * S_NW * 16 * 4, 0);
+    o.rows.assign((size_t)n_tb * S_NW * 16 * 4, 0);
+    o.hdr.assign((size_t)n_tb * S_NW * 4, 0);
     o.ent.resize((size_t)(o.n_groups + S_K) * 64 * 4);
     for (size_t i = 0; i < o.ent.size(); i += 2) {
         o.ent[i] = S_ZERO_OFF;
@@ -184,30 +196,35 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     // pass 2: records and entries
     parallel_tiles(n_tiles, nt, [&](int t, unsigned k) {
         TileScan& s = scans[k];
-        scan_tile(ptr, idx, n_dst, t, s);
+        scan_tile(ptr, idx, o.tile_row, t, s);
         const int tb0 = o.tile_blk[t];
         int64_t cur[S_NW];
-        for (int w = 0; w < S_NW; ++w) cur[w] = base[(size_t)t * S_NW + w] * 4;
+        for (int w = 0; w < S_NW; ++w) cur[w] = base[(size_t)t * S_NW + w] * 2;
         for (size_t bi = 0; bi < s.blocks.size(); ++bi) {
             const int blk = s.blocks[bi];
             o.blk_id[tb0 + bi] = blk;
             const int* ord = &s.order[bi * S_R];
             for (int w = 0; w < S_NW; ++w) {
-                const int p0 = w, p1 = S_PAIRS - 1 - w;
-                const int n0 = pass_steps(s, bi, p0), n1 = pass_steps(s, bi, p1);
-                const int64_t S = cur[w];
-                int* rec = &o.rec[(((size_t)(tb0 + bi) * S_NW + w) * 16) * 4];
-                for (int q = 0; q < 16; ++q) {
-                    rec[q * 4 + 0] = ord[32 * p0 + q] | ord[32 * p0 + 16 + q] << 16;
-                    rec[q * 4 + 1] = ord[32 * p1 + q] | ord[32 * p1 + 16 + q] << 16;
-                    rec[q * 4 + 2] = (int)S;
-                    rec[q * 4 + 3] = n0 | n1 << 16;
+                int n[2] = {0, 0};
+                int* rows = &o.rows[(((size_t)(tb0 + bi) * S_NW + w) * 16) * 4];
+                int64_t S = cur[w];
+                for (int j = 0; j < S_P; ++j) {
+                    const int p = s_bundle(w, j);
+                    n[j] = pass_steps(s, bi, p);
+                    for (int q = 0; q < 16; ++q) {
+                        rows[q * 4 + 2 * j] = ord[64 * p + q] | ord[64 * p + 16 + q] << 16;
+                        rows[q * 4 + 2 * j + 1] = ord[64 * p + 32 + q] | ord[64 * p + 48 + q] << 16;
+                    }
+                    for (int slot = 0; slot < 4; ++slot)
+                        fill_slot(idx, val, blk, s, bi, ord + 64 * p + 16 * slot, S, slot, o.ent.data());
+                    S += n[j];
                 }
-                fill_half(idx, val, blk, s, bi, ord + 32 * p0, S, 0, o.ent.data());
-                fill_half(idx, val, blk, s, bi, ord + 32 * p0 + 16, S, 1, o.ent.data());
-                fill_half(idx, val, blk, s, bi, ord + 32 * p1, S + n0, 0, o.ent.data());
-                fill_half(idx, val, blk, s, bi, ord + 32 * p1 + 16, S + n0, 1, o.ent.data());
-                cur[w] += n0 + n1;
+                int* hdr = &o.hdr[((size_t)(tb0 + bi) * S_NW + w) * 4];
+                hdr[0] = (int)cur[w];
+                hdr[1] = n[0] | n[1] << 16;
+                hdr[2] = blk;
+                hdr[3] = 0;
+                cur[w] = S;
             }
         }
     });
@@ -221,33 +238,34 @@ int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, cons
         for (int tb = s.tile_blk[t]; tb < s.tile_blk[t + 1]; ++tb) {
             const int64_t c0 = (int64_t)s.blk_id[tb] * S_CB;
             for (int w = 0; w < S_NW; ++w) {
-                const int* rec = &s.rec[(((size_t)tb * S_NW + w) * 16) * 4];
-                const int64_t S = rec[2];
-                const int n0 = rec[3] & 0xffff, n1 = (int)((unsigned)rec[3] >> 16);
+                const int* hdr = &s.hdr[((size_t)tb * S_NW + w) * 4];
+                const int n[2] = {hdr[1] & 0xffff, (int)((unsigned)hdr[1] >> 16)};
                 for (int q = 0; q < 16; ++q) {
-                    if (rec[q * 4 + 2] != rec[2] || rec[q * 4 + 3] != rec[3]) return -1;
-                    for (int pass = 0; pass < 2; ++pass) {
-                        const int rows = rec[q * 4 + pass];
-                        const int64_t a = pass ? S + n0 : S, b = pass ? S + n0 + n1 : S + n0;
+                    const int* rows = &s.rows[(((size_t)tb * S_NW + w) * 16 + q) * 4];
+                    int64_t a = hdr[0];
+                    for (int pass = 0; pass < S_P; ++pass) {
+                        const int64_t b = a + n[pass];
                         for (int64_t st = a; st < b; ++st) {
-                            if ((st >> 2) >= s.n_groups) return -1;
-                            const int* e = &s.ent[(size_t)(((st >> 2) * 64 + q * 4 + (st & 3)) * 4)];
-                            for (int half = 0; half < 2; ++half) {
-                                const int off = e[half * 2];
+                            if ((st >> 1) >= s.n_groups) return -1;
+                            for (int slot = 0; slot < 4; ++slot) {
+                                const int* e = &s.ent[(size_t)((((st >> 1) * 64 + q * 4 + slot) * 4) + (st & 1) * 2)];
+                                const int off = e[0];
                                 if (off == S_ZERO_OFF) {
-                                    if (e[half * 2 + 1] != 0) return -1;
+                                    if (e[1] != 0) return -1;
                                     continue;
                                 }
                                 if (off < 0 || off % S_ROW_BYTES || off >= S_ZERO_OFF) return -1;
                                 const int64_t col = c0 + off / S_ROW_BYTES;
-                                const int64_t row = (int64_t)t * S_R + (half ? (rows >> 16) & 0xffff : rows & 0xffff);
-                                if (col >= n_src || row >= n_dst) return -1;
+                                const int rr = rows[2 * pass + (slot >> 1)];
+                                const int64_t row = (int64_t)s.tile_row[t] + ((slot & 1) ? (rr >> 16) & 0xffff : rr & 0xffff);
+                                if (col >= n_src || row >= s.tile_row[t + 1] || row >= n_dst) return -1;
                                 float v;
-                                std::memcpy(&v, &e[half * 2 + 1], 4);
+                                std::memcpy(&v, &e[1], 4);
                                 for (int c = 0; c < 16; ++c) Y[row * 16 + c] += (double)v * (double)H[col * 16 + c];
                                 ++real;
                             }
                         }
+                        a = b;
                     }
                 }
             }

@@ -15,16 +15,22 @@ struct HostStream {
     int64_t n_groups = 0;            // groups of 4 steps (without the S_K padding groups at the end)
     int64_t real_slots = 0;          // = nnz
     int64_t step_slots = 0;          // 128 x groups: entry slots of the stream (padding included)
+    std::vector<int> tile_row;       // [n_tiles + 1]
     std::vector<int> tile_blk;       // [n_tiles + 1]
     std::vector<int> blk_id;         // [n_tb]
-    std::vector<int> rec;            // [n_tb * 8 * 16 * 4]
+    std::vector<int> rows;           // [n_tb * 8 * 16 * 4]
+    std::vector<int> hdr;            // [n_tb * 8 * 4]
     std::vector<int> ent;            // [(n_groups + S_K) * 64 * 4]
 };
 
+// Row tiles of at most S_R rows that never cross a segment boundary (seg_ptr: [n_seg + 1] ascending row offsets of the
+// LP instances, first 0, last n_dst; null = one segment).
+std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst);
+
 // 0 on success, an MLLP_E* code with *err set otherwise (sizes beyond int32 steps).  max_threads = 0: hardware
 // concurrency, at most 16.
-int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src, HostStream* out,
-                      std::string* err, unsigned max_threads = 0);
+int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
+                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads = 0);
 
 // Y[n_dst,16] (double) += the product, computed by walking the copy the way spmm_stream_kernel does (records, passes,
 // steps, groups); returns the number of real (non-padding) entries visited, -1 on a malformed copy.

@@ -46,9 +46,11 @@ struct StreamCopy {
     int n_tiles = 0, n_tb = 0;
     int64_t n_groups = 0;       // groups of 4 steps, without the S_K padding groups at the end
     int64_t step_slots = 0;     // 128 x groups: entry slots of the stream, padding included
+    int* tile_row = nullptr;    // [n_tiles + 1]
     int* tile_blk = nullptr;    // [n_tiles + 1]
     int* blk_id = nullptr;      // [n_tb]
-    int* rec = nullptr;         // [n_tb * 8 * 16] int4
+    int* rows = nullptr;        // [n_tb * 8 * 16] int4
+    int* hdr = nullptr;         // [n_tb * 8] int4
     int* ent = nullptr;         // [(n_groups + S_K) * 64] int4
     double build_seconds = 0.0;
 };
@@ -179,7 +181,7 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
-int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_t s);   // stream_build.hip
+int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s);   // stream_build.hip
 void stream_copy_free(StreamCopy& sc);                                                  // stream_api.cpp
 int launch_spmm_stream(const StreamCopy& sc, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);

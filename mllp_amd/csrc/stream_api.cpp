@@ -10,14 +10,16 @@
 namespace mllp {
 
 void stream_copy_free(StreamCopy& sc) {
+    if (sc.tile_row) (void)hipFree(sc.tile_row);
     if (sc.tile_blk) (void)hipFree(sc.tile_blk);
     if (sc.blk_id) (void)hipFree(sc.blk_id);
-    if (sc.rec) (void)hipFree(sc.rec);
+    if (sc.rows) (void)hipFree(sc.rows);
+    if (sc.hdr) (void)hipFree(sc.hdr);
     if (sc.ent) (void)hipFree(sc.ent);
     sc = StreamCopy();
 }
 
-static int build_on_host(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_t s) {
+static int build_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t>& seg, StreamCopy& sc, hipStream_t s) {
     std::vector<int> ptr((size_t)o.n_dst + 1, 0), idx((size_t)std::max<int64_t>(nnz, 1));
     std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
     MLLP_HIP_TRY(hipStreamSynchronize(s));
@@ -28,7 +30,7 @@ static int build_on_host(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream
     }
     HostStream h;
     std::string err;
-    const int rc = host_build_stream(ptr.data(), idx.data(), val.data(), o.n_dst, o.n_src, &h, &err);
+    const int rc = host_build_stream(ptr.data(), idx.data(), val.data(), o.n_dst, o.n_src, seg.data(), (int64_t)seg.size() - 1, &h, &err);
     if (rc) return fail(rc, err);
     sc.n_tiles = h.n_tiles;
     sc.n_tb = h.n_tb;
@@ -40,8 +42,8 @@ static int build_on_host(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream
         return MLLP_OK;
     };
     int r;
-    if ((r = up(sc.tile_blk, h.tile_blk)) || (r = up(sc.blk_id, h.blk_id)) || (r = up(sc.rec, h.rec)) ||
-        (r = up(sc.ent, h.ent)))
+    if ((r = up(sc.tile_row, h.tile_row)) || (r = up(sc.tile_blk, h.tile_blk)) || (r = up(sc.blk_id, h.blk_id)) ||
+        (r = up(sc.rows, h.rows)) || (r = up(sc.hdr, h.hdr)) || (r = up(sc.ent, h.ent)))
         return r;
     return MLLP_OK;
 }
@@ -61,8 +63,10 @@ extern "C" int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int wh
     if (o.n_dst == 0) return MLLP_OK;
     const auto t0 = std::chrono::steady_clock::now();
     StreamCopy sc;
-    const int rc = where == 1 ? build_on_host(o, g->nnz, sc, (hipStream_t)stream)
-                              : build_stream_device(o, g->nnz, sc, (hipStream_t)stream);
+    const std::vector<int64_t>& seg = transpose ? g->h_inst_ptr_n : g->h_inst_ptr_m;     // tiles stay inside an instance
+    const int rc = where == 1 ? build_on_host(o, g->nnz, seg, sc, (hipStream_t)stream)
+                              : build_stream_device(o, g->nnz, host_stream_tiles(seg.data(), (int64_t)seg.size() - 1, o.n_dst),
+                                                    sc, (hipStream_t)stream);
     if (rc) {
         stream_copy_free(sc);
         return rc;
@@ -85,7 +89,7 @@ extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, i
     info[1] = sc.n_tb;
     info[2] = sc.n_groups;
     info[3] = sc.step_slots;
-    info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 4 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * S_NW * 256 +
+    info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 8 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * S_NW * (256 + 16) +
                                (sc.n_groups + S_K) * 1024
                          : 0;                                   // bytes of the copy
     info[5] = (int64_t)(sc.build_seconds * 1e6);                // microseconds the build took (host clock, synchronised)
@@ -104,9 +108,11 @@ extern "C" int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose,
     switch (which) {
         case 0: src = sc.tile_blk; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
         case 1: src = sc.blk_id; bytes = (int64_t)sc.n_tb * 4; break;
-        case 2: src = sc.rec; bytes = (int64_t)sc.n_tb * S_NW * 256; break;
+        case 2: src = sc.rows; bytes = (int64_t)sc.n_tb * S_NW * 256; break;
         case 3: src = sc.ent; bytes = (sc.n_groups + S_K) * 1024; break;
-        default: return fail(MLLP_EINVAL, "mllp_graph_export_spmm_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rec) or 3 (ent)");
+        case 4: src = sc.tile_row; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
+        case 5: src = sc.hdr; bytes = (int64_t)sc.n_tb * S_NW * 16; break;
+        default: return fail(MLLP_EINVAL, "mllp_graph_export_spmm_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rows), 3 (ent), 4 (tile_row) or 5 (hdr)");
     }
     REQUIRE(capacity_bytes >= bytes, "destination too small");
     MLLP_HIP_TRY(hipDeviceSynchronize());

@@ -11,7 +11,7 @@
 //   sb_wave_totals / sb_step_starts   position of every (tile, block, wavefront) record in the entry stream
 //   sb_fill_padding   the whole stream = padding entries
 //   sb_fill           records + the real entries: one thread per TEAM (4 rows that are read in one LDS cycle), jointly
-//                     ordered over (column mod 4) exactly as host_stream.cpp::fill_half does
+//                     ordered over (column mod 4) exactly as host_stream.cpp::fill_slot does
 // Three small arrays (per-tile ranges, block counts, per-(tile, wavefront) group counts) are scanned on the host.
 #include <algorithm>
 #include <climits>
@@ -26,15 +26,16 @@ void stream_copy_free(StreamCopy& sc);
 
 namespace {
 
-constexpr int SB_T = 512;       // threads = rows of a tile
+constexpr int SB_T = S_R;       // threads = rows of a tile
 
-__global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ ptr, const int* __restrict__ idx, int n_dst,
-                                                      int* __restrict__ lo, int* __restrict__ hi) {
+__global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                      const int* __restrict__ tile_row, int* __restrict__ lo,
+                                                      int* __restrict__ hi) {
     __shared__ int s_lo, s_hi;
     if (threadIdx.x == 0) { s_lo = INT_MAX; s_hi = -1; }
     __syncthreads();
-    const int r = blockIdx.x * S_R + threadIdx.x;
-    if (r < n_dst) {
+    const int r = tile_row[blockIdx.x] + threadIdx.x;
+    if (r < tile_row[blockIdx.x + 1]) {
         const int b = ptr[r], e = ptr[r + 1];
         if (e > b) {
             atomicMin(&s_lo, idx[b] / S_CB);
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ pt
 }
 
 // bm: bitmap words of every tile, tile t at bm_off[t] (ceil((hi - lo + 1) / 32) words)
-__global__ __launch_bounds__(SB_T) void sb_tile_bitmap(const int* __restrict__ ptr, const int* __restrict__ idx, int n_dst,
-                                                       const int* __restrict__ lo, const int* __restrict__ hi,
+__global__ __launch_bounds__(SB_T) void sb_tile_bitmap(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                       const int* __restrict__ tile_row, const int* __restrict__ lo, const int* __restrict__ hi,
                                                        const int* __restrict__ bm_off, unsigned* __restrict__ bm,
                                                        int* __restrict__ nb) {
     extern __shared__ unsigned s_bm[];
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(SB_T) void sb_tile_bitmap(const int* __restrict__ p
     for (int i = threadIdx.x; i < words; i += SB_T) s_bm[i] = 0u;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const int r = t * S_R + threadIdx.x;
-    if (r < n_dst) {
+    const int r = tile_row[t] + threadIdx.x;
+    if (r < tile_row[t + 1]) {
         int last = -1;
         for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
             const int b = idx[e] / S_CB;
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(64) void sb_tile_blocks(const int* __restrict__ lo,
     }
 }
 
-__global__ __launch_bounds__(SB_T) void sb_count_rows(const int* __restrict__ ptr, const int* __restrict__ idx, int n_dst,
-                                                      const int* __restrict__ lo, const int* __restrict__ bm_off,
+__global__ __launch_bounds__(SB_T) void sb_count_rows(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                      const int* __restrict__ tile_row, const int* __restrict__ lo, const int* __restrict__ bm_off,
                                                       const unsigned* __restrict__ bm, const int* __restrict__ bm_pref,
                                                       const int* __restrict__ tile_blk, int* __restrict__ cnt,
                                                       int* __restrict__ start) {
-    const int t = blockIdx.x, r = t * S_R + threadIdx.x;
-    if (r >= n_dst) return;
+    const int t = blockIdx.x, r = tile_row[t] + threadIdx.x;
+    if (r >= tile_row[t + 1]) return;
     const int l = lo[t], off = bm_off[t], tb0 = tile_blk[t];
     int last = -1, c = 0;
     size_t slot = 0;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(SB_T) void sb_count_rows(const int* __restrict__ pt
     if (c) cnt[slot] = c;
 }
 
-// order[tb][k] = row with the k-th most entries (ties by row); npass[tb][w] = n0 | n1 << 16
+// order[tb][k] = row with the k-th most entries (ties by row); npass[tb][w][2] = {n0 | n1 << 16, n2 | n3 << 16}
 __global__ __launch_bounds__(SB_T) void sb_sort_rows(const int* __restrict__ cnt, int* __restrict__ order,
                                                      int* __restrict__ npass) {
     __shared__ int c[S_R], ord[S_R];
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(SB_T) void sb_sort_rows(const int* __restrict__ cnt
     order[tb * S_R + rank] = r;
     __syncthreads();
     if (r < S_NW) {
-        const int n0 = c[ord[32 * r]], n1 = c[ord[32 * (S_PAIRS - 1 - r)]];
-        npass[tb * S_NW + r] = n0 | n1 << 16;
+        int n[2] = {0, 0};
+        for (int j = 0; j < S_P; ++j) n[j] = c[ord[64 * s_bundle(r, j)]];
+        npass[(tb * S_NW + r) * 2] = n[0] | n[1] << 16;
+        npass[(tb * S_NW + r) * 2 + 1] = 0;
     }
 }
 
@@ -169,10 +172,10 @@ __global__ void sb_wave_totals(const int* __restrict__ tile_blk, const int* __re
     const int t = i / S_NW, w = i % S_NW;
     long long steps = 0;
     for (int tb = tile_blk[t]; tb < tile_blk[t + 1]; ++tb) {
-        const unsigned v = (unsigned)npass[(size_t)tb * S_NW + w];
-        steps += (v & 0xffffu) + (v >> 16);
+        const unsigned v = (unsigned)npass[((size_t)tb * S_NW + w) * 2], u = (unsigned)npass[((size_t)tb * S_NW + w) * 2 + 1];
+        steps += (v & 0xffffu) + (v >> 16) + (u & 0xffffu) + (u >> 16);
     }
-    groups[i] = (int)((steps + 3) >> 2);
+    groups[i] = (int)((steps + 1) >> 1);
 }
 
 __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __restrict__ npass, int n_tiles,
@@ -180,11 +183,11 @@ __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * S_NW) return;
     const int t = i / S_NW, w = i % S_NW;
-    int run = base_group[i] * 4;
+    int run = base_group[i] * 2;
     for (int tb = tile_blk[t]; tb < tile_blk[t + 1]; ++tb) {
-        const unsigned v = (unsigned)npass[(size_t)tb * S_NW + w];
+        const unsigned v = (unsigned)npass[((size_t)tb * S_NW + w) * 2], u = (unsigned)npass[((size_t)tb * S_NW + w) * 2 + 1];
         step_start[(size_t)tb * S_NW + w] = run;
-        run += (int)((v & 0xffffu) + (v >> 16));
+        run += (int)((v & 0xffffu) + (v >> 16) + (u & 0xffffu) + (u >> 16));
     }
 }
 
@@ -194,27 +197,29 @@ __global__ void sb_fill_padding(int4* __restrict__ ent, long long n) {
         ent[i] = pad;
 }
 
-// thread = (wavefront w, pass, half A / B, team): the joint ordering of host_stream.cpp::fill_half for its four rows;
-// the first 128 threads also write the records
-__global__ __launch_bounds__(128) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
-                                               const int* __restrict__ blk_id, const int* __restrict__ cnt,
-                                               const int* __restrict__ start, const int* __restrict__ order,
-                                               const int* __restrict__ npass, const int* __restrict__ step_start,
-                                               int4* __restrict__ rec, int* __restrict__ ent) {
+// thread = (wavefront w, pass j, row slot, team): the joint ordering of host_stream.cpp::fill_slot for its four rows;
+// the first 128 threads also write the row records, the first 8 the headers
+__global__ __launch_bounds__(S_NW * S_P * 16) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
+                                                           const int* __restrict__ blk_id, const int* __restrict__ cnt,
+                                                           const int* __restrict__ start, const int* __restrict__ order,
+                                                           const int* __restrict__ npass, const int* __restrict__ step_start,
+                                                           int4* __restrict__ rows_out, int4* __restrict__ hdr_out,
+                                                           int* __restrict__ ent) {
     const size_t tb = blockIdx.x;
     const int tid = threadIdx.x;
     const int* ord = order + tb * S_R;
-    {
+    if (tid < S_NW * 16) {
         const int w = tid >> 4, q = tid & 15;
-        const int p0 = w, p1 = S_PAIRS - 1 - w;
-        rec[(tb * S_NW + w) * 16 + q] =
-            make_int4(ord[32 * p0 + q] | ord[32 * p0 + 16 + q] << 16, ord[32 * p1 + q] | ord[32 * p1 + 16 + q] << 16,
-                      step_start[tb * S_NW + w], npass[tb * S_NW + w]);
+        const int p0 = s_bundle(w, 0), p1 = s_bundle(w, 1);
+        rows_out[(tb * S_NW + w) * 16 + q] =
+            make_int4(ord[64 * p0 + q] | ord[64 * p0 + 16 + q] << 16, ord[64 * p0 + 32 + q] | ord[64 * p0 + 48 + q] << 16,
+                      ord[64 * p1 + q] | ord[64 * p1 + 16 + q] << 16, ord[64 * p1 + 32 + q] | ord[64 * p1 + 48 + q] << 16);
     }
-    const int w = tid >> 4, pass = (tid >> 3) & 1, half = (tid >> 2) & 1, tm = tid & 3;
-    const int pair = pass ? S_PAIRS - 1 - w : w;
-    const unsigned np = (unsigned)npass[tb * S_NW + w];
-    const long long S = (long long)step_start[tb * S_NW + w] + (pass ? (int)(np & 0xffffu) : 0);
+    if (tid < S_NW) hdr_out[tb * S_NW + tid] = make_int4(step_start[tb * S_NW + tid], npass[(tb * S_NW + tid) * 2], blk_id[tb], 0);
+    const int w = tid >> 5, pass = (tid >> 4) & 1, slot = (tid >> 2) & 3, tm = tid & 3;
+    const int bundle = s_bundle(w, pass);
+    const unsigned np0 = (unsigned)npass[(tb * S_NW + w) * 2];
+    const long long S = (long long)step_start[tb * S_NW + w] + (pass ? (int)(np0 & 0xffffu) : 0);
     const int blk = blk_id[tb];
     const int c0 = blk * S_CB;
     int beg[4], rem[4], nxt[4][4], cl[4][4], quad[4];
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(128) void sb_fill(const int* __restrict__ idx, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         quad[i] = S_TEAMS[tm][i];
-        const int r = ord[32 * pair + 16 * half + quad[i]];
+        const int r = ord[64 * bundle + 16 * slot + quad[i]];
         beg[i] = start[tb * S_R + r];
         rem[i] = cnt[tb * S_R + r];
 #pragma unroll
@@ -262,9 +267,9 @@ __global__ __launch_bounds__(128) void sb_fill(const int* __restrict__ idx, cons
                 rem[i] -= 1;
                 used |= 1u << pick;
                 const long long step = S + p;
-                int* slot = ent + (((step >> 2) * 64 + quad[i] * 4 + (step & 3)) * 4 + half * 2);
-                slot[0] = (idx[beg[i] + e] - c0) * S_ROW_BYTES;
-                slot[1] = __float_as_int(val[beg[i] + e]);
+                int* dst = ent + (((step >> 1) * 64 + quad[i] * 4 + slot) * 4 + (step & 1) * 2);
+                dst[0] = (idx[beg[i] + e] - c0) * S_ROW_BYTES;
+                dst[1] = __float_as_int(val[beg[i] + e]);
             }
         }
     }
@@ -279,15 +284,16 @@ struct DevBuf {
 
 }  // namespace
 
-int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_t s) {
+int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s) {
     (void)nnz;
-    const int n_tiles = (int)(((int64_t)o.n_dst + S_R - 1) / S_R);
-    if (n_tiles >= (1 << 28)) return fail(MLLP_ERANGE, "streamed copy: too many row tiles");
+    const int n_tiles = (int)tile_row.size() - 1;
+    MLLP_HIP_TRY(hipMalloc((void**)&sc.tile_row, ((size_t)n_tiles + 1) * 4));
+    MLLP_HIP_TRY(hipMemcpyAsync(sc.tile_row, tile_row.data(), ((size_t)n_tiles + 1) * 4, hipMemcpyHostToDevice, s));
     DevBuf<int> lo, hi, bm_off, nb, bm_pref, cnt, start, order, npass, groups, base, sstart;
     DevBuf<unsigned> bm;
     if (lo.alloc(n_tiles) || hi.alloc(n_tiles) || bm_off.alloc(n_tiles) || nb.alloc(n_tiles))
         return fail(MLLP_ENOMEM, "streamed copy: hipMalloc failed");
-    hipLaunchKernelGGL(sb_tile_range, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, o.n_dst, lo.p, hi.p);
+    hipLaunchKernelGGL(sb_tile_range, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, hi.p);
     std::vector<int> h_lo(n_tiles), h_hi(n_tiles), h_off(n_tiles), h_nb(n_tiles);
     MLLP_HIP_TRY(hipMemcpyAsync(h_lo.data(), lo.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
     MLLP_HIP_TRY(hipMemcpyAsync(h_hi.data(), hi.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
@@ -309,8 +315,8 @@ int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_
     if (words_max * 4 > 48 * 1024)
         MLLP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sb_tile_bitmap),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, words_max * 4));
-    hipLaunchKernelGGL(sb_tile_bitmap, dim3(n_tiles), dim3(SB_T), (size_t)words_max * 4, s, o.ptr, o.idx, o.n_dst, lo.p,
-                       hi.p, bm_off.p, bm.p, nb.p);
+    hipLaunchKernelGGL(sb_tile_bitmap, dim3(n_tiles), dim3(SB_T), (size_t)words_max * 4, s, o.ptr, o.idx, sc.tile_row,
+                       lo.p, hi.p, bm_off.p, bm.p, nb.p);
     MLLP_HIP_TRY(hipMemcpyAsync(h_nb.data(), nb.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
     MLLP_HIP_TRY(hipStreamSynchronize(s));
     std::vector<int> h_tile_blk((size_t)n_tiles + 1, 0);
@@ -325,17 +331,18 @@ int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_
     sc.n_tb = (int)n_tb;
     MLLP_HIP_TRY(hipMalloc((void**)&sc.tile_blk, ((size_t)n_tiles + 1) * 4));
     MLLP_HIP_TRY(hipMalloc((void**)&sc.blk_id, std::max<size_t>(n_tb, 1) * 4));
-    MLLP_HIP_TRY(hipMalloc((void**)&sc.rec, std::max<size_t>(n_tb, 1) * S_NW * 256));
+    MLLP_HIP_TRY(hipMalloc((void**)&sc.rows, std::max<size_t>(n_tb, 1) * S_NW * 256));
+    MLLP_HIP_TRY(hipMalloc((void**)&sc.hdr, std::max<size_t>(n_tb, 1) * S_NW * 16));
     MLLP_HIP_TRY(hipMemcpyAsync(sc.tile_blk, h_tile_blk.data(), ((size_t)n_tiles + 1) * 4, hipMemcpyHostToDevice, s));
     const size_t n_slots = (size_t)n_tb * S_R;
-    if (cnt.alloc(n_slots) || start.alloc(n_slots) || order.alloc(n_slots) || npass.alloc((size_t)n_tb * S_NW) ||
+    if (cnt.alloc(n_slots) || start.alloc(n_slots) || order.alloc(n_slots) || npass.alloc((size_t)n_tb * S_NW * 2) ||
         sstart.alloc((size_t)n_tb * S_NW) || groups.alloc((size_t)n_tiles * S_NW) || base.alloc((size_t)n_tiles * S_NW))
         return fail(MLLP_ENOMEM, "streamed copy: hipMalloc failed");
     MLLP_HIP_TRY(hipMemsetAsync(cnt.p, 0, std::max<size_t>(n_slots, 1) * 4, s));
     MLLP_HIP_TRY(hipMemsetAsync(start.p, 0, std::max<size_t>(n_slots, 1) * 4, s));
     hipLaunchKernelGGL(sb_tile_blocks, dim3(n_tiles), dim3(64), 0, s, lo.p, hi.p, bm_off.p, bm.p, sc.tile_blk, sc.blk_id,
                        bm_pref.p);
-    hipLaunchKernelGGL(sb_count_rows, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, o.n_dst, lo.p, bm_off.p, bm.p,
+    hipLaunchKernelGGL(sb_count_rows, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, bm_off.p, bm.p,
                        bm_pref.p, sc.tile_blk, cnt.p, start.p);
     if (n_tb > 0) hipLaunchKernelGGL(sb_sort_rows, dim3((unsigned)n_tb), dim3(SB_T), 0, s, cnt.p, order.p, npass.p);
     const int nw = n_tiles * S_NW;
@@ -347,7 +354,7 @@ int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_
     for (int i = 0; i < nw; ++i) {
         h_base[i] = (int)n_groups;
         n_groups += h_groups[i];
-        if (n_groups * 4 >= ((int64_t)1 << 31) - 4 * S_K) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
+        if (n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
     }
     sc.n_groups = n_groups;
     MLLP_HIP_TRY(hipMemcpyAsync(base.p, h_base.data(), (size_t)nw * 4, hipMemcpyHostToDevice, s));
@@ -357,8 +364,9 @@ int build_stream_device(const Orient& o, int64_t nnz, StreamCopy& sc, hipStream_
     MLLP_HIP_TRY(hipMalloc((void**)&sc.ent, (size_t)n_ent * 16));
     hipLaunchKernelGGL(sb_fill_padding, dim3(4096), dim3(256), 0, s, reinterpret_cast<int4*>(sc.ent), n_ent);
     if (n_tb > 0)
-        hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(128), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p, order.p,
-                           npass.p, sstart.p, reinterpret_cast<int4*>(sc.rec), sc.ent);
+        hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(S_NW * S_P * 16), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
+                           order.p, npass.p, sstart.p, reinterpret_cast<int4*>(sc.rows), reinterpret_cast<int4*>(sc.hdr),
+                           sc.ent);
     MLLP_HIP_TRY(hipGetLastError());
     sc.step_slots = n_groups * 128;      // entry slots of the stream, padding included
     MLLP_HIP_TRY(hipStreamSynchronize(s));

@@ -5,47 +5,60 @@
 // nonzeros of a (512-row tile, 1024-column block) in a 48 KB LDS window next to ONE 64 KB image of H, so the walkers
 // stood idle while the next image was written (24.5 % of the kernel, profiles/r02_spmm_ws_phase_cycles.txt) and every
 // nonzero cost 16 bytes of LDS write + read traffic on top of its 64-byte H row.  Here the nonzeros never enter LDS:
-//   * the builder stores them in the order the walker LANES consume them, so a walker wavefront reads its share
-//     of a (tile, block) straight into registers with coalesced 1 KB loads, one block ahead;
+//   * the builder stores them in the order the LANES consume them, so a wavefront reads its share of a
+//     (tile, block) straight into registers with coalesced 1 KB loads, one block ahead;
 //   * LDS then holds TWO images of H (filled by LDS-DMA, no registers) + the tile's accumulators: image b + 1
 //     lands while image b is walked; one barrier per block.
 //
-// Geometry: row tiles of S_R = 512 destination rows x column blocks of S_CB = 1000 source nodes (64 000 B of fp32
-// rows; 2 x (64 000 + one all-zero row) + 32 KB of accumulators = 160 896 B of the CU's 163 840 B of LDS).
+// Geometry: row tiles of at most S_R = 1024 destination rows x column blocks of S_CB = 625 source nodes.  The first
+// version (512 x 1000) measured bound by the CU's vector-memory fill path, not by LDS (profiles/r03_stream_*): every
+// tile stages every block of its instance, 6400 / S_R bytes of H per nonzero at 1 % density whatever S_CB is, most of
+// it L2 hits but 40 % of them misses (the hot H of the 2-3 instances an XCD works on does not fit its 4 MB L2 next to
+// the entry stream).  1024 rows halve that traffic; 64 KB of accumulators + 2 x (40 000 B + one all-zero row) of
+// images = 145 664 B of LDS.  Tiles never cross an instance boundary (tile_row): a tile that straddles two instances
+// would stage the blocks of both for half the rows each.
 //
 // Work split inside a (tile, block): the rows are ordered by their number of entries in the block (descending, ties
-// by row id) and cut into 16 PAIRS of 32 positions.  Walker wavefront w (of S_NW = 8) walks pair w in its pass 0 and
-// pair 15 - w in its pass 1 (long rows with short rows: equal step counts for all wavefronts).  In a pass, quad q of
-// the wavefront owns two rows, A = position 32 p + q and B = position 32 p + 16 + q; a STEP is one entry of A and one
-// of B for each of the 16 quads; the pass takes n = (entries of the pair's longest row) steps, shorter rows are
-// padded with entries {S_ZERO_OFF, 0.0f} that read the all-zero row behind the image.
+// by row id) and cut into S_NB = 16 BUNDLES of 64 positions.  Wavefront w (of S_NW = 8) walks S_P = 2 passes, pass j
+// over bundle 8 j + (j odd ? 7 - w : w) (long rows with short rows: equal step counts for all wavefronts).  In a
+// pass, quad q of the wavefront owns FOUR rows, slot r = position 64 b + 16 r + q (16 independent ds_read_b128 per
+// wavefront and step keep the LDS busy: the first version, two rows per quad and four passes, waited for LDS round
+// trips 80 % of its walk); a STEP is one entry of each of the four rows for each of the 16 quads; the pass takes
+// n = (entries of the bundle's longest row) steps, shorter rows are padded with entries {S_ZERO_OFF, 0.0f} that read
+// the all-zero row behind the image (8 % of the slots on the synthetic batch).
 //
 // Arrays:
+//   tile_row [n_tiles + 1]   first destination row of each tile (rows of tile t: tile_row[t] .. tile_row[t + 1] - 1)
 //   tile_blk [n_tiles + 1]   first (tile, block) index of each tile
 //   blk_id   [n_tb]          global column-block id of each (tile, block), ascending inside a tile
-//   rec      [n_tb][8][16]   int4 per (tile-block, wavefront, quad):
-//                              .x = row A | row B << 16 of pass 0 (rows inside the tile),  .y = the same for pass 1,
-//                              .z = index of the wavefront's first step of this block in `ent`,
-//                              .w = n0 | n1 << 16 (steps of pass 0 / pass 1; the same in all 16 quads)
-//   ent      [(n_groups + S_K) * 64] int4: a GROUP is four consecutive steps = 1 KB; lane 4 q + p of a wavefront
-//                              loads int4 number group * 64 + 4 q + p = step 4 group + p of quad q:
-//                              {byte offset of A's source row in the image, value bits, the same for B}.
+//   rows     [n_tb][8][16]   int4 per (tile-block, wavefront, quad): {row0 | row1 << 16, row2 | row3 << 16} of pass 0
+//                            in .x .y, of pass 1 in .z .w (rows inside the tile)
+//   hdr      [n_tb][8]       int4 per (tile-block, wavefront): .x = index of the wavefront's first step of this block
+//                            in `ent`, .y = n0 | n1 << 16 (steps of the two passes), .z = blk_id of the block, .w = 0
+//   ent      [(n_groups + S_K) * 64] int4: a GROUP is two consecutive steps = 1 KB; lane 4 q + r of a wavefront
+//                            loads int4 number group * 64 + 4 q + r = row slot r of quad q:
+//                              {byte offset of the source row in the image, value bits} of step 2 group, then the
+//                              same of step 2 group + 1.
 //                            The steps of a (tile, wavefront) are contiguous over its blocks (pass 0 then pass 1 of
 //                            each block) and start at a group boundary; S_K padding groups at the very end let the
-//                            walkers load S_K groups unconditionally.
+//                            wavefronts load S_K groups unconditionally.
 #pragma once
 #include <stdint.h>
 
 namespace mllp {
 
-constexpr int S_R = 512;                    // rows per tile
-constexpr int S_CB = 1000;                  // source nodes per column block
-constexpr int S_NW = 8;                     // walker wavefronts per workgroup
-constexpr int S_PAIRS = S_R / 32;           // 16 pairs of 32 sorted positions
-constexpr int S_K = 8;                      // groups (of 4 steps) of a block that a walker holds in registers
+constexpr int S_R = 1024;                   // rows per tile (at most)
+constexpr int S_CB = 625;                   // source nodes per column block
+constexpr int S_NW = 8;                     // wavefronts per workgroup
+constexpr int S_NB = S_R / 64;              // bundles of 64 sorted positions
+constexpr int S_P = S_NB / S_NW;            // passes per wavefront and block
+constexpr int S_K = 12;                     // groups (of 2 steps) of a block that a wavefront holds in registers
 constexpr int S_ROW_BYTES = 64;             // one fp32 feature row
 constexpr int S_ZERO_OFF = S_CB * S_ROW_BYTES;   // byte offset of the all-zero row behind the image
-static_assert(S_PAIRS == 2 * S_NW, "two passes per walker");
+static_assert(S_P * S_NW == S_NB && S_P == 2 && S_R <= 1024, "two passes per wavefront");
+
+// bundle of sorted positions that wavefront w walks in its pass j
+constexpr int s_bundle(int w, int j) { return S_NW * j + ((j & 1) ? S_NW - 1 - w : w); }
 
 // the four quads whose rows are read in the same LDS cycle of a ds_read_b128 (lane groups {0-3,12-15,20-27},
 // {4-11,16-19,28-31} and the same + 32: MI355X_MICROARCH.md, LDS): their source rows should sit in four different

@@ -45,7 +45,7 @@ for tr in (False, True):
     print(f"  device build {time.time()-t0:.3f}s", info, f"slots/nnz={info['entry_slots']/b.nnz:.4f}", flush=True)
     if host is not None:
         dev = b.export_spmm_copy(tr)
-        for name, a, d in zip(("tile_blk", "blk_id", "rec", "ent"), host, dev):
+        for name, a, d in zip(("tile_blk", "blk_id", "rows", "ent", "tile_row", "hdr"), host, dev):
             same = a.shape == d.shape and np.array_equal(a, d)
             print(f"    {name}: host == device: {same}", "" if same else f"(first diff at {np.flatnonzero(a.ravel() != d.ravel())[:4] if a.shape == d.shape else (a.shape, d.shape)})")
         del host, dev

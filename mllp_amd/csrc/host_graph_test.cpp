@@ -283,7 +283,7 @@ static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_de
         for (int64_t sgm : seg) CHECK(!(sgm > a.tile_row[t] && sgm < a.tile_row[t + 1]));      // no tile crosses a segment
     }
     CHECK((int)a.tile_blk.size() == a.n_tiles + 1 && a.tile_blk[a.n_tiles] == a.n_tb);
-    CHECK(a.ent.size() == (size_t)(a.n_groups + S_K) * 256 && a.real_slots == (int64_t)idx.size());
+    CHECK(a.ent.size() == (size_t)(a.n_groups + S_K0) * 64 * S_ENT && a.real_slots == (int64_t)idx.size());
     CHECK(a.step_slots >= a.real_slots);
     std::vector<double> Y((size_t)n_dst * 16, 0.0), Yref((size_t)n_dst * 16, 0.0);
     CHECK(host_walk_stream(a, n_dst, n_src, H.data(), Y.data()) == (int64_t)idx.size());
@@ -380,7 +380,7 @@ int main(int argc, char** argv) {
         std::string err;
         const int p0[1] = {0};
         CHECK(host_build_stream(p0, nullptr, nullptr, 0, 10, nullptr, 0, &e, &err) == MLLP_OK && e.n_tiles == 0 && e.n_groups == 0);
-        CHECK(e.ent.size() == (size_t)S_K * 256);
+        CHECK(e.ent.size() == (size_t)S_K0 * 64 * S_ENT);
     }
     {   // empty batch and argument errors
         HostBatch b;

@@ -105,9 +105,10 @@ void fill_slot(const int* idx, const float* val, int blk, const TileScan& s, siz
                 used |= 1u << pick;
                 const int64_t step = S + p;
                 const int q = S_TEAMS[tm][i];
-                int* dst = ent + (((step >> 1) * 64 + q * 4 + slot) * 4 + (step & 1) * 2);
-                dst[0] = (idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
-                std::memcpy(&dst[1], &val[c.beg + e], 4);
+                int* dst = ent + ((step >> 1) * 64 + q * 4 + slot) * S_ENT;
+                const unsigned o16 = (unsigned)(idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
+                dst[0] = (step & 1) ? (int)(((unsigned)dst[0] & 0xffffu) | o16 << 16) : (int)(((unsigned)dst[0] & 0xffff0000u) | o16);
+                std::memcpy(&dst[1 + (step & 1)], &val[c.beg + e], 4);
             }
         }
     }
@@ -182,14 +183,14 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     }
     o.n_groups = base[steps.size()];
     o.step_slots = o.n_groups * 128;
-    if (o.n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
+    if (o.n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K0) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
     o.blk_id.assign(n_tb, 0);
     o.rows.assign((size_t)n_tb * S_NW * 16 * 4, 0);
     o.hdr.assign((size_t)n_tb * S_NW * 4, 0);
-    o.ent.resize((size_t)(o.n_groups + S_K) * 64 * 4);
-    for (size_t i = 0; i < o.ent.size(); i += 2) {
-        o.ent[i] = S_ZERO_OFF;
-        o.ent[i + 1] = 0;
+    o.ent.resize((size_t)(o.n_groups + S_K0) * 64 * S_ENT);
+    for (size_t i = 0; i < o.ent.size(); i += S_ENT) {
+        o.ent[i] = S_PAD_WORD;
+        o.ent[i + 1] = o.ent[i + 2] = 0;
     }
     o.real_slots = n_dst ? ptr[n_dst] : 0;
 
@@ -248,8 +249,9 @@ int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, cons
                         for (int64_t st = a; st < b; ++st) {
                             if ((st >> 1) >= s.n_groups) return -1;
                             for (int slot = 0; slot < 4; ++slot) {
-                                const int* e = &s.ent[(size_t)((((st >> 1) * 64 + q * 4 + slot) * 4) + (st & 1) * 2)];
-                                const int off = e[0];
+                                const int* g = &s.ent[(size_t)(((st >> 1) * 64 + q * 4 + slot) * S_ENT)];
+                                const int off = (int)(((unsigned)g[0] >> ((st & 1) * 16)) & 0xffffu);
+                                const int* e = g + (st & 1);         // e[1] = value bits
                                 if (off == S_ZERO_OFF) {
                                     if (e[1] != 0) return -1;
                                     continue;

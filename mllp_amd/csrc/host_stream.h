@@ -12,7 +12,7 @@ namespace mllp {
 
 struct HostStream {
     int n_tiles = 0, n_tb = 0;
-    int64_t n_groups = 0;            // groups of 4 steps (without the S_K padding groups at the end)
+    int64_t n_groups = 0;            // groups of 2 steps (without the padding groups at the end)
     int64_t real_slots = 0;          // = nnz
     int64_t step_slots = 0;          // 128 x groups: entry slots of the stream (padding included)
     std::vector<int> tile_row;       // [n_tiles + 1]
@@ -20,7 +20,7 @@ struct HostStream {
     std::vector<int> blk_id;         // [n_tb]
     std::vector<int> rows;           // [n_tb * 8 * 16 * 4]
     std::vector<int> hdr;            // [n_tb * 8 * 4]
-    std::vector<int> ent;            // [(n_groups + S_K) * 64 * 4]
+    std::vector<int> ent;            // [(n_groups + S_K0) * 64 * S_ENT]
 };
 
 // Row tiles of at most S_R rows that never cross a segment boundary (seg_ptr: [n_seg + 1] ascending row offsets of the

@@ -44,14 +44,14 @@ struct Tiled {
 // streamed copy of an orientation (stream_layout.h): library-owned device arrays, built by mllp_graph_build_spmm_copy
 struct StreamCopy {
     int n_tiles = 0, n_tb = 0;
-    int64_t n_groups = 0;       // groups of 4 steps, without the S_K padding groups at the end
+    int64_t n_groups = 0;       // groups of 2 steps, without the padding groups at the end
     int64_t step_slots = 0;     // 128 x groups: entry slots of the stream, padding included
     int* tile_row = nullptr;    // [n_tiles + 1]
     int* tile_blk = nullptr;    // [n_tiles + 1]
     int* blk_id = nullptr;      // [n_tb]
     int* rows = nullptr;        // [n_tb * 8 * 16] int4
     int* hdr = nullptr;         // [n_tb * 8] int4
-    int* ent = nullptr;         // [(n_groups + S_K) * 64] int4
+    int* ent = nullptr;         // [(n_groups + S_K0) * 64 * S_ENT]
     double build_seconds = 0.0;
 };
 

@@ -90,7 +90,7 @@ extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, i
     info[2] = sc.n_groups;
     info[3] = sc.step_slots;
     info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 8 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * S_NW * (256 + 16) +
-                               (sc.n_groups + S_K) * 1024
+                               (sc.n_groups + S_K0) * 64 * S_ENT * 4
                          : 0;                                   // bytes of the copy
     info[5] = (int64_t)(sc.build_seconds * 1e6);                // microseconds the build took (host clock, synchronised)
     info[6] = S_R;
@@ -109,7 +109,7 @@ extern "C" int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose,
         case 0: src = sc.tile_blk; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
         case 1: src = sc.blk_id; bytes = (int64_t)sc.n_tb * 4; break;
         case 2: src = sc.rows; bytes = (int64_t)sc.n_tb * S_NW * 256; break;
-        case 3: src = sc.ent; bytes = (sc.n_groups + S_K) * 1024; break;
+        case 3: src = sc.ent; bytes = (sc.n_groups + S_K0) * 64 * S_ENT * 4; break;
         case 4: src = sc.tile_row; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
         case 5: src = sc.hdr; bytes = (int64_t)sc.n_tb * S_NW * 16; break;
         default: return fail(MLLP_EINVAL, "mllp_graph_export_spmm_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rows), 3 (ent), 4 (tile_row) or 5 (hdr)");

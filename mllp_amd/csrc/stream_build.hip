@@ -191,10 +191,10 @@ __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __re
     }
 }
 
-__global__ void sb_fill_padding(int4* __restrict__ ent, long long n) {
-    const int4 pad = make_int4(S_ZERO_OFF, 0, S_ZERO_OFF, 0);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        ent[i] = pad;
+// n = number of (group, lane) items of S_ENT ints
+__global__ void sb_fill_padding(int* __restrict__ ent, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n * S_ENT; i += (long long)gridDim.x * blockDim.x)
+        ent[i] = (i % S_ENT) == 0 ? S_PAD_WORD : 0;
 }
 
 // thread = (wavefront w, pass j, row slot, team): the joint ordering of host_stream.cpp::fill_slot for its four rows;
@@ -267,9 +267,11 @@ __global__ __launch_bounds__(S_NW * S_P * 16) void sb_fill(const int* __restrict
                 rem[i] -= 1;
                 used |= 1u << pick;
                 const long long step = S + p;
-                int* dst = ent + (((step >> 1) * 64 + quad[i] * 4 + slot) * 4 + (step & 1) * 2);
-                dst[0] = (idx[beg[i] + e] - c0) * S_ROW_BYTES;
-                dst[1] = __float_as_int(val[beg[i] + e]);
+                // (the two halves of the offset word may belong to different passes / blocks, i.e. to different
+                // threads: two-byte stores, no read-modify-write)
+                int* dst = ent + ((step >> 1) * 64 + quad[i] * 4 + slot) * S_ENT;
+                reinterpret_cast<unsigned short*>(dst)[step & 1] = (unsigned short)((idx[beg[i] + e] - c0) * S_ROW_BYTES);
+                dst[1 + (step & 1)] = __float_as_int(val[beg[i] + e]);
             }
         }
     }
@@ -354,15 +356,15 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     for (int i = 0; i < nw; ++i) {
         h_base[i] = (int)n_groups;
         n_groups += h_groups[i];
-        if (n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
+        if (n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K0) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
     }
     sc.n_groups = n_groups;
     MLLP_HIP_TRY(hipMemcpyAsync(base.p, h_base.data(), (size_t)nw * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(sb_step_starts, dim3((nw + 255) / 256), dim3(256), 0, s, sc.tile_blk, npass.p, n_tiles, base.p,
                        sstart.p);
-    const long long n_ent = (long long)(n_groups + S_K) * 64;
-    MLLP_HIP_TRY(hipMalloc((void**)&sc.ent, (size_t)n_ent * 16));
-    hipLaunchKernelGGL(sb_fill_padding, dim3(4096), dim3(256), 0, s, reinterpret_cast<int4*>(sc.ent), n_ent);
+    const long long n_ent = (long long)(n_groups + S_K0) * 64;
+    MLLP_HIP_TRY(hipMalloc((void**)&sc.ent, (size_t)n_ent * S_ENT * 4));
+    hipLaunchKernelGGL(sb_fill_padding, dim3(4096), dim3(256), 0, s, sc.ent, n_ent);
     if (n_tb > 0)
         hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(S_NW * S_P * 16), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
                            order.p, npass.p, sstart.p, reinterpret_cast<int4*>(sc.rows), reinterpret_cast<int4*>(sc.hdr),

@@ -24,7 +24,7 @@
 // pass, quad q of the wavefront owns FOUR rows, slot r = position 64 b + 16 r + q (16 independent ds_read_b128 per
 // wavefront and step keep the LDS busy: the first version, two rows per quad and four passes, waited for LDS round
 // trips 80 % of its walk); a STEP is one entry of each of the four rows for each of the 16 quads; the pass takes
-// n = (entries of the bundle's longest row) steps, shorter rows are padded with entries {S_ZERO_OFF, 0.0f} that read
+// n = (entries of the bundle's longest row) steps, shorter rows are padded with entries {zero row, 0.0f} that read
 // the all-zero row behind the image (8 % of the slots on the synthetic batch).
 //
 // Arrays:
@@ -35,13 +35,14 @@
 //                            in .x .y, of pass 1 in .z .w (rows inside the tile)
 //   hdr      [n_tb][8]       int4 per (tile-block, wavefront): .x = index of the wavefront's first step of this block
 //                            in `ent`, .y = n0 | n1 << 16 (steps of the two passes), .z = blk_id of the block, .w = 0
-//   ent      [(n_groups + S_K) * 64] int4: a GROUP is two consecutive steps = 1 KB; lane 4 q + r of a wavefront
-//                            loads int4 number group * 64 + 4 q + r = row slot r of quad q:
-//                              {byte offset of the source row in the image, value bits} of step 2 group, then the
-//                              same of step 2 group + 1.
+//   ent      [(n_groups + S_K0) * 64 * 3] int32: a GROUP is two consecutive steps = 768 B; lane 4 q + r of a
+//                            wavefront loads the 12 bytes number group * 64 + 4 q + r = row slot r of quad q:
+//                              {o(step 2 group) | o(step 2 group + 1) << 16, value bits of the first, of the second}
+//                            with o = byte offset of the source row in the image (< 2^16): 6 bytes per nonzero instead
+//                            of CSR's 8.
 //                            The steps of a (tile, wavefront) are contiguous over its blocks (pass 0 then pass 1 of
-//                            each block) and start at a group boundary; S_K padding groups at the very end let the
-//                            wavefronts load S_K groups unconditionally.
+//                            each block) and start at a group boundary; S_K0 padding groups at the very end let the
+//                            wavefronts load their register sets unconditionally.
 #pragma once
 #include <stdint.h>
 
@@ -52,9 +53,12 @@ constexpr int S_CB = 625;                   // source nodes per column block
 constexpr int S_NW = 8;                     // wavefronts per workgroup
 constexpr int S_NB = S_R / 64;              // bundles of 64 sorted positions
 constexpr int S_P = S_NB / S_NW;            // passes per wavefront and block
-constexpr int S_K = 12;                     // groups (of 2 steps) of a block that a wavefront holds in registers
+constexpr int S_K0 = 9, S_K1 = 4;           // groups (of 2 steps) of pass 0 / pass 1 that a wavefront holds in registers
+constexpr int S_ENT = 3;                    // int32 per (group, lane)
 constexpr int S_ROW_BYTES = 64;             // one fp32 feature row
 constexpr int S_ZERO_OFF = S_CB * S_ROW_BYTES;   // byte offset of the all-zero row behind the image
+constexpr int S_PAD_WORD = S_ZERO_OFF | S_ZERO_OFF << 16;    // offset word of two padding entries
+static_assert(S_ZERO_OFF + S_ROW_BYTES <= 65536, "byte offsets inside the image are stored in 16 bits");
 static_assert(S_P * S_NW == S_NB && S_P == 2 && S_R <= 1024, "two passes per wavefront");
 
 // bundle of sorted positions that wavefront w walks in its pass j

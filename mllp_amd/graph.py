@@ -301,11 +301,11 @@ class LPBatch:
         return dict(zip(keys, [int(v) for v in d]))
 
     def export_spmm_copy(self, transpose=False):
-        """(tile_blk, blk_id, rows [n_tb, 8, 16, 4], ent [groups + padding, 64, 4], tile_row, hdr [n_tb, 8, 4]) as
+        """(tile_blk, blk_id, rows [n_tb, 8, 16, 4], ent [groups + padding, 64, 3], tile_row, hdr [n_tb, 8, 4]) as
         numpy int32 arrays (tests)."""
         i = self.spmm_copy_info(transpose)
-        n_ent_groups = (i["bytes"] - (i["n_tiles"] + 1) * 8 - i["n_tb"] * 4 - i["n_tb"] * 8 * 272) // 1024
-        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], 8, 16, 4), (n_ent_groups, 64, 4),
+        n_ent_groups = (i["bytes"] - (i["n_tiles"] + 1) * 8 - i["n_tb"] * 4 - i["n_tb"] * 8 * 272) // 768
+        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], 8, 16, 4), (n_ent_groups, 64, 3),
                   (i["n_tiles"] + 1,), (i["n_tb"], 8, 4)]
         out = []
         for which, shp in enumerate(shapes):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown and ablation timings of the streamed SpMM kernel.  Needs the TIMING library
 (`make -C mllp_amd/csrc timing`); the product library has no such switch.
-usage: python3 tools/stream_cycles.py [instances]"""
+usage: python3 tools/stream_cycles.py [instances] [both]"""
 import os, sys
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -11,34 +11,48 @@ _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", "libmllp_hip_timing.so")
 from mllp_amd.graph import synthetic_batch
 
 n_inst = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+both = len(sys.argv) > 2 and sys.argv[2] == "both"
 b = synthetic_batch(n_inst)
 
+
 def timed(fn, reps=10):
-    for _ in range(2): fn()
+    for _ in range(2):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-for tr in (False, True):
+
+ABL = ((0, "full"), (1, "no walk (loads + staging + barriers)"), (2, "no staging"))
+ROLES = (("walkers (8 wavefronts)", 0, 8, ["prologue", "wait at the barrier", "walk", "prefetch issue"]),
+         ("stagers (4 wavefronts)", 16, 4, ["LDS-DMA issue + pacing + landing", "wait at the barrier", "-", "-"]))
+for tr in ((False, True) if both else (False,)):
     n_in, n_out = (b.M, b.N) if tr else (b.N, b.M)
-    H = torch.randn(n_in, 16, device="cuda"); Y = torch.zeros(n_out, 16, device="cuda")
+    H = torch.randn(n_in, 16, device="cuda")
+    Y = torch.zeros(n_out, 16, device="cuda")
     info = b.build_spmm_copy(tr, "device")
     n_tiles, n_tb = info["n_tiles"], info["n_tb"]
     print(f"transpose={tr} tiles={n_tiles} blocks={n_tb} nnz/block={b.nnz / n_tb:.0f} slots/nnz={info['entry_slots'] / b.nnz:.4f}")
-    for abl, name in ((0, "full"), (1, "no walk (loads + staging + barriers)"), (2, "no staging"), (3, "no walk, no staging")):
+    for abl, name in ABL:
         os.environ["MLLP_STREAM_ABLATION"] = str(abl)
         print(f"   {name:40s} {timed(lambda: b.spmm(H, transpose=tr, out=Y)):.3f} ms")
-    os.environ["MLLP_STREAM_ABLATION"] = "16"
-    for _ in range(2):
-        b.spmm(H, transpose=tr, out=Y)
-    torch.cuda.synchronize()
-    c = Y[0:2 * n_tiles:2, :].double().cpu()        # [tiles, 16]
-    names = ["wait for the prefetch to land", "wait at the barrier", "walk", "prefetch issue"]
-    tot = c[:, 4].sum()
-    print(f"  8 wavefronts: {tot / 8 / n_tiles:10.0f} cycles per tile, {tot / 8 / n_tb:8.0f} per block")
-    for k in range(4):
-        print(f"     {names[k]:30s} {c[:, k].sum() / tot * 100:6.1f} %   {c[:, k].sum() / 8 / n_tb:8.0f} cycles per block")
+    for stamp in (16, 28, 48, 80, 92):
+        os.environ["MLLP_STREAM_ABLATION"] = str(stamp)
+        print(f"  -- stamps, ablation bits {stamp - 16} (4 = no LDS reads, 8 = no FMAs, 32 = entry reloads hit the cache, 64 = no entry reloads)")
+        for _ in range(2):
+            b.spmm(H, transpose=tr, out=Y)
+        torch.cuda.synchronize()
+        c = torch.cat([Y[0:2 * n_tiles:2, :].double().cpu(), Y[1:2 * n_tiles:2, :].double().cpu()], 1)   # [tiles, 32]
+        for title, o, nw, names in ROLES:
+            tot = c[:, o + 4].sum()
+            print(f"  {title}: {tot / nw / n_tiles:10.0f} cycles per tile, {tot / nw / n_tb:8.0f} per block")
+            for k in range(4):
+                if names[k] != "-":
+                    print(f"     {names[k]:34s} {c[:, o + k].sum() / tot * 100:6.1f} %   {c[:, o + k].sum() / nw / n_tb:8.0f} cycles per block")
     os.environ["MLLP_STREAM_ABLATION"] = "0"
     b.drop_spmm_copy(tr)

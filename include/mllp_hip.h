@@ -119,7 +119,8 @@ int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf1
  *   where: 0 = built on the device (counting + placement kernels), 1 = built by the host reference builder
  *          (same bytes; tests compare the two).
  *   mllp_graph_spmm_copy_info: info[0..7] = row tiles, (tile, block) pairs, 1 KB entry groups, entry slots (padding
- *          included; compare with nnz), bytes of the copy, microseconds the build took, rows per tile, columns per block.
+ *          included; compare with nnz), bytes of the copy, microseconds the build took, rows per tile, columns per block
+ *          | wavefronts per tile << 16.
  *   mllp_graph_export_spmm_copy (tests): which = 0 tile_blk (int32, tiles + 1), 1 blk_id (int32), 2 row records
  *          (int32 x 4 per (tile-block, wavefront, quad)), 3 entry stream (int32 x 4 per (group, lane)), 4 tile_row
  *          (int32, tiles + 1), 5 headers (int32 x 4 per (tile-block, wavefront)).                                 */

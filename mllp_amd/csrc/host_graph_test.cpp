@@ -301,14 +301,12 @@ static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_de
                 const int* hdr = &a.hdr[((size_t)tb * S_NW + w) * 4];
                 const int* rows = &a.rows[(((size_t)tb * S_NW + w) * 16) * 4];
                 if (next[w] >= 0) CHECK(hdr[0] == next[w]);
-                else CHECK(hdr[0] % 2 == 0);
+                else CHECK(hdr[0] % S_GS == 0);
                 CHECK(hdr[2] == a.blk_id[tb] && hdr[3] == 0);
                 next[w] = (int64_t)hdr[0] + (hdr[1] & 0xffff) + (int)((unsigned)hdr[1] >> 16);
                 for (int q = 0; q < 16; ++q)
-                    for (int k = 0; k < 4; ++k) {
-                        seen[rows[q * 4 + k] & 0xffff]++;
-                        seen[(rows[q * 4 + k] >> 16) & 0xffff]++;
-                    }
+                    for (int j = 0; j < S_P; ++j)
+                        for (int r = 0; r < S_RQ; ++r) seen[(rows[q * 4 + 2 * j + (r >> 1)] >> (16 * (r & 1))) & 0xffff]++;
             }
             for (int r = 0; r < S_R; ++r) CHECK(seen[r] == 1);
         }

@@ -58,7 +58,7 @@ void scan_tile(const int* ptr, const int* idx, const std::vector<int>& tile_row,
 }
 
 inline int pass_steps(const TileScan& s, size_t bi, int bundle) {     // entries of the bundle's longest row
-    return s.cnt[bi * S_R + s.order[bi * S_R + 64 * bundle]];
+    return s.cnt[bi * S_R + s.order[bi * S_R + S_BR * bundle]];
 }
 
 // one row of a team during the joint ordering
@@ -105,7 +105,7 @@ void fill_slot(const int* idx, const float* val, int blk, const TileScan& s, siz
                 used |= 1u << pick;
                 const int64_t step = S + p;
                 const int q = S_TEAMS[tm][i];
-                int* dst = ent + ((step >> 1) * 64 + q * 4 + slot) * S_ENT;
+                int* dst = ent + s_ent_index(step, q, slot);
                 const unsigned o16 = (unsigned)(idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
                 dst[0] = (step & 1) ? (int)(((unsigned)dst[0] & 0xffffu) | o16 << 16) : (int)(((unsigned)dst[0] & 0xffff0000u) | o16);
                 std::memcpy(&dst[1 + (step & 1)], &val[c.beg + e], 4);
@@ -179,11 +179,11 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     o.n_tb = (int)n_tb;
     std::vector<int64_t> base((size_t)n_tiles * S_NW + 1, 0);     // first group of every (tile, wavefront)
     for (size_t i = 0; i < steps.size(); ++i) {
-        base[i + 1] = base[i] + (steps[i] + 1) / 2;
+        base[i + 1] = base[i] + (steps[i] + S_GS - 1) / S_GS;
     }
     o.n_groups = base[steps.size()];
-    o.step_slots = o.n_groups * 128;
-    if (o.n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K0) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
+    o.step_slots = o.n_groups * 128;     // 64 lanes x 2 entries per group
+    if (o.n_groups * S_GS >= ((int64_t)1 << 31) - S_GS * S_K0) return bad(MLLP_ERANGE, "host_build_stream: more than 2^31 steps");
     o.blk_id.assign(n_tb, 0);
     o.rows.assign((size_t)n_tb * S_NW * 16 * 4, 0);
     o.hdr.assign((size_t)n_tb * S_NW * 4, 0);
@@ -200,7 +200,7 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
         scan_tile(ptr, idx, o.tile_row, t, s);
         const int tb0 = o.tile_blk[t];
         int64_t cur[S_NW];
-        for (int w = 0; w < S_NW; ++w) cur[w] = base[(size_t)t * S_NW + w] * 2;
+        for (int w = 0; w < S_NW; ++w) cur[w] = base[(size_t)t * S_NW + w] * S_GS;
         for (size_t bi = 0; bi < s.blocks.size(); ++bi) {
             const int blk = s.blocks[bi];
             o.blk_id[tb0 + bi] = blk;
@@ -212,12 +212,11 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
                 for (int j = 0; j < S_P; ++j) {
                     const int p = s_bundle(w, j);
                     n[j] = pass_steps(s, bi, p);
-                    for (int q = 0; q < 16; ++q) {
-                        rows[q * 4 + 2 * j] = ord[64 * p + q] | ord[64 * p + 16 + q] << 16;
-                        rows[q * 4 + 2 * j + 1] = ord[64 * p + 32 + q] | ord[64 * p + 48 + q] << 16;
-                    }
-                    for (int slot = 0; slot < 4; ++slot)
-                        fill_slot(idx, val, blk, s, bi, ord + 64 * p + 16 * slot, S, slot, o.ent.data());
+                    for (int q = 0; q < 16; ++q)
+                        for (int r = 0; r < S_RQ; ++r)
+                            rows[q * 4 + 2 * j + (r >> 1)] |= ord[S_BR * p + 16 * r + q] << (16 * (r & 1));
+                    for (int slot = 0; slot < S_RQ; ++slot)
+                        fill_slot(idx, val, blk, s, bi, ord + S_BR * p + 16 * slot, S, slot, o.ent.data());
                     S += n[j];
                 }
                 int* hdr = &o.hdr[((size_t)(tb0 + bi) * S_NW + w) * 4];
@@ -247,9 +246,9 @@ int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, cons
                     for (int pass = 0; pass < S_P; ++pass) {
                         const int64_t b = a + n[pass];
                         for (int64_t st = a; st < b; ++st) {
-                            if ((st >> 1) >= s.n_groups) return -1;
-                            for (int slot = 0; slot < 4; ++slot) {
-                                const int* g = &s.ent[(size_t)(((st >> 1) * 64 + q * 4 + slot) * S_ENT)];
+                            if (st / S_GS >= s.n_groups) return -1;
+                            for (int slot = 0; slot < S_RQ; ++slot) {
+                                const int* g = &s.ent[(size_t)s_ent_index(st, q, slot)];
                                 const int off = (int)(((unsigned)g[0] >> ((st & 1) * 16)) & 0xffffu);
                                 const int* e = g + (st & 1);         // e[1] = value bits
                                 if (off == S_ZERO_OFF) {

@@ -94,7 +94,7 @@ extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, i
                          : 0;                                   // bytes of the copy
     info[5] = (int64_t)(sc.build_seconds * 1e6);                // microseconds the build took (host clock, synchronised)
     info[6] = S_R;
-    info[7] = S_CB;
+    info[7] = S_CB | S_NW << 16;
     return MLLP_OK;
 }
 

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(SB_T) void sb_sort_rows(const int* __restrict__ cnt
     __syncthreads();
     if (r < S_NW) {
         int n[2] = {0, 0};
-        for (int j = 0; j < S_P; ++j) n[j] = c[ord[64 * s_bundle(r, j)]];
+        for (int j = 0; j < S_P; ++j) n[j] = c[ord[S_BR * s_bundle(r, j)]];
         npass[(tb * S_NW + r) * 2] = n[0] | n[1] << 16;
         npass[(tb * S_NW + r) * 2 + 1] = 0;
     }
@@ -175,7 +175,7 @@ __global__ void sb_wave_totals(const int* __restrict__ tile_blk, const int* __re
         const unsigned v = (unsigned)npass[((size_t)tb * S_NW + w) * 2], u = (unsigned)npass[((size_t)tb * S_NW + w) * 2 + 1];
         steps += (v & 0xffffu) + (v >> 16) + (u & 0xffffu) + (u >> 16);
     }
-    groups[i] = (int)((steps + 1) >> 1);
+    groups[i] = (int)((steps + S_GS - 1) / S_GS);
 }
 
 __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __restrict__ npass, int n_tiles,
@@ -183,7 +183,7 @@ __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * S_NW) return;
     const int t = i / S_NW, w = i % S_NW;
-    int run = base_group[i] * 2;
+    int run = base_group[i] * S_GS;
     for (int tb = tile_blk[t]; tb < tile_blk[t + 1]; ++tb) {
         const unsigned v = (unsigned)npass[((size_t)tb * S_NW + w) * 2], u = (unsigned)npass[((size_t)tb * S_NW + w) * 2 + 1];
         step_start[(size_t)tb * S_NW + w] = run;
@@ -198,25 +198,27 @@ __global__ void sb_fill_padding(int* __restrict__ ent, long long n) {
 }
 
 // thread = (wavefront w, pass j, row slot, team): the joint ordering of host_stream.cpp::fill_slot for its four rows;
-// the first 128 threads also write the row records, the first 8 the headers
-__global__ __launch_bounds__(S_NW * S_P * 16) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
-                                                           const int* __restrict__ blk_id, const int* __restrict__ cnt,
-                                                           const int* __restrict__ start, const int* __restrict__ order,
-                                                           const int* __restrict__ npass, const int* __restrict__ step_start,
-                                                           int4* __restrict__ rows_out, int4* __restrict__ hdr_out,
-                                                           int* __restrict__ ent) {
+// the first S_NW x 16 threads also write the row records, the first S_NW the headers
+constexpr int SB_FILL_T = S_NW * S_P * S_RQ * 4;
+static_assert(SB_FILL_T >= S_NW * 16 && SB_FILL_T <= 1024, "sb_fill threads");
+__global__ __launch_bounds__(SB_FILL_T) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
+                                                     const int* __restrict__ blk_id, const int* __restrict__ cnt,
+                                                     const int* __restrict__ start, const int* __restrict__ order,
+                                                     const int* __restrict__ npass, const int* __restrict__ step_start,
+                                                     int4* __restrict__ rows_out, int4* __restrict__ hdr_out,
+                                                     int* __restrict__ ent) {
     const size_t tb = blockIdx.x;
     const int tid = threadIdx.x;
     const int* ord = order + tb * S_R;
     if (tid < S_NW * 16) {
         const int w = tid >> 4, q = tid & 15;
-        const int p0 = s_bundle(w, 0), p1 = s_bundle(w, 1);
-        rows_out[(tb * S_NW + w) * 16 + q] =
-            make_int4(ord[64 * p0 + q] | ord[64 * p0 + 16 + q] << 16, ord[64 * p0 + 32 + q] | ord[64 * p0 + 48 + q] << 16,
-                      ord[64 * p1 + q] | ord[64 * p1 + 16 + q] << 16, ord[64 * p1 + 32 + q] | ord[64 * p1 + 48 + q] << 16);
+        int r4[4] = {0, 0, 0, 0};
+        for (int j = 0; j < S_P; ++j)
+            for (int r = 0; r < S_RQ; ++r) r4[2 * j + (r >> 1)] |= ord[S_BR * s_bundle(w, j) + 16 * r + q] << (16 * (r & 1));
+        rows_out[(tb * S_NW + w) * 16 + q] = make_int4(r4[0], r4[1], r4[2], r4[3]);
     }
     if (tid < S_NW) hdr_out[tb * S_NW + tid] = make_int4(step_start[tb * S_NW + tid], npass[(tb * S_NW + tid) * 2], blk_id[tb], 0);
-    const int w = tid >> 5, pass = (tid >> 4) & 1, slot = (tid >> 2) & 3, tm = tid & 3;
+    const int w = tid / (S_P * S_RQ * 4), pass = (tid / (S_RQ * 4)) % S_P, slot = (tid >> 2) % S_RQ, tm = tid & 3;
     const int bundle = s_bundle(w, pass);
     const unsigned np0 = (unsigned)npass[(tb * S_NW + w) * 2];
     const long long S = (long long)step_start[tb * S_NW + w] + (pass ? (int)(np0 & 0xffffu) : 0);
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(S_NW * S_P * 16) void sb_fill(const int* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         quad[i] = S_TEAMS[tm][i];
-        const int r = ord[64 * bundle + 16 * slot + quad[i]];
+        const int r = ord[S_BR * bundle + 16 * slot + quad[i]];
         beg[i] = start[tb * S_R + r];
         rem[i] = cnt[tb * S_R + r];
 #pragma unroll
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(S_NW * S_P * 16) void sb_fill(const int* __restrict
                 const long long step = S + p;
                 // (the two halves of the offset word may belong to different passes / blocks, i.e. to different
                 // threads: two-byte stores, no read-modify-write)
-                int* dst = ent + ((step >> 1) * 64 + quad[i] * 4 + slot) * S_ENT;
+                int* dst = ent + s_ent_index(step, quad[i], slot);
                 reinterpret_cast<unsigned short*>(dst)[step & 1] = (unsigned short)((idx[beg[i] + e] - c0) * S_ROW_BYTES);
                 dst[1 + (step & 1)] = __float_as_int(val[beg[i] + e]);
             }
@@ -356,7 +358,7 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     for (int i = 0; i < nw; ++i) {
         h_base[i] = (int)n_groups;
         n_groups += h_groups[i];
-        if (n_groups * 2 >= ((int64_t)1 << 31) - 2 * S_K0) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
+        if (n_groups * S_GS >= ((int64_t)1 << 31) - S_GS * S_K0) return fail(MLLP_ERANGE, "streamed copy: more than 2^31 steps");
     }
     sc.n_groups = n_groups;
     MLLP_HIP_TRY(hipMemcpyAsync(base.p, h_base.data(), (size_t)nw * 4, hipMemcpyHostToDevice, s));
@@ -366,7 +368,7 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     MLLP_HIP_TRY(hipMalloc((void**)&sc.ent, (size_t)n_ent * S_ENT * 4));
     hipLaunchKernelGGL(sb_fill_padding, dim3(4096), dim3(256), 0, s, sc.ent, n_ent);
     if (n_tb > 0)
-        hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(S_NW * S_P * 16), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
+        hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(SB_FILL_T), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
                            order.p, npass.p, sstart.p, reinterpret_cast<int4*>(sc.rows), reinterpret_cast<int4*>(sc.hdr),
                            sc.ent);
     MLLP_HIP_TRY(hipGetLastError());

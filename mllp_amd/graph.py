@@ -298,15 +298,19 @@ class LPBatch:
         d = (c_int64 * 8)()
         _lib.check(_lib.lib().mllp_graph_spmm_copy_info(self._h, int(transpose), d))
         keys = ["n_tiles", "n_tb", "n_groups", "entry_slots", "bytes", "build_us", "rows_per_tile", "cols_per_block"]
-        return dict(zip(keys, [int(v) for v in d]))
+        out = dict(zip(keys, [int(v) for v in d]))
+        out["wavefronts"] = out["cols_per_block"] >> 16          # packed: wavefronts << 16 | columns per block
+        out["cols_per_block"] &= 0xffff
+        return out
 
     def export_spmm_copy(self, transpose=False):
         """(tile_blk, blk_id, rows [n_tb, 8, 16, 4], ent [groups + padding, 64, 3], tile_row, hdr [n_tb, 8, 4]) as
         numpy int32 arrays (tests)."""
         i = self.spmm_copy_info(transpose)
-        n_ent_groups = (i["bytes"] - (i["n_tiles"] + 1) * 8 - i["n_tb"] * 4 - i["n_tb"] * 8 * 272) // 768
-        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], 8, 16, 4), (n_ent_groups, 64, 3),
-                  (i["n_tiles"] + 1,), (i["n_tb"], 8, 4)]
+        nw = i["wavefronts"]
+        n_ent_groups = (i["bytes"] - (i["n_tiles"] + 1) * 8 - i["n_tb"] * 4 - i["n_tb"] * nw * 272) // 768
+        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], nw, 16, 4), (n_ent_groups, 64, 3),
+                  (i["n_tiles"] + 1,), (i["n_tb"], nw, 4)]
         out = []
         for which, shp in enumerate(shapes):
             a = np.empty(shp, dtype=np.int32)

@@ -29,8 +29,7 @@ def timed(fn, reps=10):
 
 
 ABL = ((0, "full"), (1, "no walk (loads + staging + barriers)"), (2, "no staging"))
-ROLES = (("walkers (8 wavefronts)", 0, 8, ["prologue", "wait at the barrier", "walk", "prefetch issue"]),
-         ("stagers (4 wavefronts)", 16, 4, ["LDS-DMA issue + pacing + landing", "wait at the barrier", "-", "-"]))
+ROLES = (("16 wavefronts", 0, 16, ["wait for the prefetch to land", "wait at the barrier", "walk", "top of the block"]),)
 for tr in ((False, True) if both else (False,)):
     n_in, n_out = (b.M, b.N) if tr else (b.N, b.M)
     H = torch.randn(n_in, 16, device="cuda")
@@ -41,13 +40,13 @@ for tr in ((False, True) if both else (False,)):
     for abl, name in ABL:
         os.environ["MLLP_STREAM_ABLATION"] = str(abl)
         print(f"   {name:40s} {timed(lambda: b.spmm(H, transpose=tr, out=Y)):.3f} ms")
-    for stamp in (16, 28, 48, 80, 92):
+    for stamp in (16, 28, 272, 284):
         os.environ["MLLP_STREAM_ABLATION"] = str(stamp)
-        print(f"  -- stamps, ablation bits {stamp - 16} (4 = no LDS reads, 8 = no FMAs, 32 = entry reloads hit the cache, 64 = no entry reloads)")
+        print(f"  -- stamps, ablation bits {stamp - 16} (4 = no LDS reads, 8 = no FMAs, 64 = no entry reloads, 256 = only wavefront 0 walks: its time = 16 x the walk figure)")
         for _ in range(2):
             b.spmm(H, transpose=tr, out=Y)
         torch.cuda.synchronize()
-        c = torch.cat([Y[0:2 * n_tiles:2, :].double().cpu(), Y[1:2 * n_tiles:2, :].double().cpu()], 1)   # [tiles, 32]
+        c = Y[0:2 * n_tiles:2, :].double().cpu()   # [tiles, 16]
         for title, o, nw, names in ROLES:
             tot = c[:, o + 4].sum()
             print(f"  {title}: {tot / nw / n_tiles:10.0f} cycles per tile, {tot / nw / n_tb:8.0f} per block")

@@ -53,13 +53,13 @@ namespace mllp {
 
 constexpr int S_R = 1024;                   // rows per tile (at most)
 constexpr int S_CB = 625;                   // source nodes per column block
-constexpr int S_NW = 16;                    // wavefronts per workgroup
-constexpr int S_RQ = 2;                     // rows per quad and pass
+constexpr int S_NW = 8;                     // walking wavefronts per workgroup
+constexpr int S_RQ = 4;                     // rows per quad and pass
 constexpr int S_GS = 8 / S_RQ;              // steps per group
 constexpr int S_BR = 16 * S_RQ;             // rows per bundle
 constexpr int S_NB = S_R / S_BR;            // bundles of sorted positions
 constexpr int S_P = S_NB / S_NW;            // passes per wavefront and block
-constexpr int S_K0 = 6, S_K1 = 3;           // groups of pass 0 / pass 1 that a wavefront holds in registers
+constexpr int S_K0 = 9, S_K1 = 4;           // groups of pass 0 / pass 1 that a wavefront holds in registers
 constexpr int S_ENT = 3;                    // int32 per (group, lane)
 constexpr int S_ROW_BYTES = 64;             // one fp32 feature row
 constexpr int S_ZERO_OFF = S_CB * S_ROW_BYTES;   // byte offset of the all-zero row behind the image

@@ -33,12 +33,14 @@
 
 namespace mllp {
 
-constexpr int SK_THREADS = 64 * S_NW;
+constexpr int SK_STAGERS = S_NW == 8 ? 4 : 0;      // separate staging wavefronts (16 walkers stage for themselves)
+constexpr int SK_THREADS = 64 * (S_NW + SK_STAGERS);
 constexpr int SK_IMG = S_CB * S_ROW_BYTES + S_ROW_BYTES;      // image + the all-zero row
 constexpr int SK_YA = 2 * SK_IMG;                             // accumulators behind the two images
 constexpr int SK_LDS = SK_YA + S_R * S_ROW_BYTES;
 constexpr int SK_PIECES = (S_CB * S_ROW_BYTES + 1023) / 1024; // LDS-DMA pieces of 1 KB per image
-constexpr int SK_PPW = (SK_PIECES + S_NW - 1) / S_NW;         // pieces per wavefront
+constexpr int SK_NSTG = SK_STAGERS ? SK_STAGERS : S_NW;       // wavefronts that stage
+constexpr int SK_PPW = (SK_PIECES + SK_NSTG - 1) / SK_NSTG;   // pieces per staging wavefront
 constexpr int SK_D = 2;         // pipeline depth in steps: D + 1 sets of read results
 static_assert(SK_LDS + 256 <= 163840 && SK_THREADS <= 1024, "one CU");
 
@@ -154,6 +156,40 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
         last_ = now_;                                                                                       \
     }
 
+    if (SK_STAGERS && wave >= S_NW) {
+        // ------------------------------------------------ stagers (8-walker configuration) ----------------
+        const int d = wave - S_NW;
+        const i32x4* hp = t.hdr + (size_t)tb0 * S_NW;          // any wavefront's header carries the block id
+        auto stage = [&](int b, int img, bool paced) {
+            const int c0 = __builtin_amdgcn_readfirstlane(hp[S_NW * b].z) * S_CB;
+            const int nbytes = min(S_CB, t.n_src - c0) * S_ROW_BYTES;
+            const char* src = reinterpret_cast<const char*>(X + (size_t)c0 * 16) + lane * 16;
+            char* img_base = smem + img * SK_IMG;
+#pragma unroll
+            for (int i = 0; i < SK_PPW; ++i) {
+                const int piece = d + SK_NSTG * i;
+                if (piece * 1024 + lane * 16 < nbytes && !(ABL & 2))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                        (__attribute__((address_space(3))) void*)(img_base + piece * 1024), 16, 0, 0);
+                if (paced) __builtin_amdgcn_s_sleep(3);      // a burst would block the walkers in their own loads
+            }
+        };
+        stage(0, 0, false);
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            if (k + 1 < nb) stage(k + 1, (k + 1) & 1, true);
+            __syncthreads();
+        }
+        if (ABL & 16) {
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            return;
+        }
+        for (int i = tid; i < n4; i += SK_THREADS) dst[i] = Ya[i];
+        return;
+    }
     const int quad = lane >> 2, part = lane & 3;
     const i32x4* rowp = t.rows + ((size_t)tb0 * S_NW + wave) * 16 + quad;     // + 16 S_NW per block
     const i32x4* hdrp = t.hdr + (size_t)tb0 * S_NW + wave;                    // + S_NW per block (wave-uniform)
@@ -164,12 +200,13 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
     auto stage_piece = [&](int blk, int img, int i) {
         const int c0 = __builtin_amdgcn_readfirstlane(blk) * S_CB;
         const int nbytes = min(S_CB, t.n_src - c0) * S_ROW_BYTES;
-        const int off = (wave + S_NW * i) * 1024;
-        if (off + lane * 16 < nbytes && !(ABL & 2))
+        const int off = (wave + SK_NSTG * i) * 1024;
+        if (!SK_STAGERS && off + lane * 16 < nbytes && !(ABL & 2))
             glds16(reinterpret_cast<const char*>(X + (size_t)c0 * 16) + off + lane * 16,
                    __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(img * SK_IMG + off)));
     };
-    for (int i = 0; i < SK_PPW; ++i) stage_piece(hc.z, 0, i);
+    if (!SK_STAGERS)
+        for (int i = 0; i < SK_PPW; ++i) stage_piece(hc.z, 0, i);
 
     Ent3 ea[S_K0], eb[S_K1];
     auto ld3 = [&](const Ent3* p) {
@@ -198,7 +235,7 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
     // (group j is reloaded behind its last step); `extra(site)`: what else the hooks issue.  Steps beyond the register
     // set (a row with dozens of entries inside one block) are fetched group by group: slow path, kept apart so that
     // the common path never waits for a load.
-    auto pass = [&](auto& cur, const Ent3* np, auto kk, int r01, int r23, int a, int b, unsigned pb, auto&& extra) {
+    auto pass = [&](auto& cur, const Ent3* np, int gn, auto kk, int r01, int r23, int a, int b, unsigned pb, auto&& extra) {
         constexpr int K = decltype(kk)::value;
         if (ABL & 1) a = b;
         if ((ABL & 256) && wave != 0) a = b;      // timing only: one wavefront walks alone
@@ -263,7 +300,9 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
                 constexpr int site = decltype(hc_)::value;
                 constexpr int h = site - (S_GS - 1) - SK_D;             // site of the last FMA of group h / S_GS
                 if constexpr (h >= 0 && h % S_GS == 0 && h / S_GS < K) {
-                    if (!(ABL & 64)) cur[h / S_GS] = ld3(np + 64 * (h / S_GS));
+                    // (only the groups the next block's pass will use: the CU's vector-memory path, ~30 B/clk, is what
+                    // bounds the kernel, and loading the whole set every block tripled the entry bytes through it)
+                    if (h / S_GS < gn && !(ABL & 64)) cur[h / S_GS] = ld3(np + 64 * (h / S_GS));
                 }
                 extra(hc_);
             });
@@ -297,6 +336,10 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
         const i32x4 h2 = hdrp[S_NW * min(k + 2, nb - 1)];
         const Ent3* npa = set_base(hn, 0);
         const Ent3* npb = set_base(hn, 1);
+        const int nS_ = __builtin_amdgcn_readfirstlane(hn.x);
+        const unsigned nc_ = (unsigned)__builtin_amdgcn_readfirstlane(hn.y);
+        const int gna = (nS_ % S_GS + (int)(nc_ & 0xffffu) + S_GS - 1) / S_GS;            // groups the next block's passes use
+        const int gnb = ((nS_ + (int)(nc_ & 0xffffu)) % S_GS + (int)(nc_ >> 16) + S_GS - 1) / S_GS;
         const bool more = k + 1 < nb;
         const int nblk = hn.z, nimg = (k + 1) & 1;
         SK_TICK(3)
@@ -304,13 +347,13 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
         const unsigned c_ = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
         const int n0_ = (int)(c_ & 0xffffu), n1_ = (int)(c_ >> 16);
         const unsigned pb_ = (unsigned)((k & 1) * SK_IMG + part * 16);
-        pass(ea, npa, std::integral_constant<int, S_K0>(), rc.x, rc.y, S_, S_ + n0_, pb_, [&](auto sc) {
+        pass(ea, npa, more ? gna : 0, std::integral_constant<int, S_K0>(), rc.x, rc.y, S_, S_ + n0_, pb_, [&](auto sc) {
             constexpr int s = decltype(sc)::value;          // the LDS-DMA pieces of the next image, one per site
-            if constexpr (s % 3 == 1 && s / 3 < SK_PPW) {
+            if constexpr (!SK_STAGERS && s % 3 == 1 && s / 3 < SK_PPW) {
                 if (more) stage_piece(nblk, nimg, s / 3);
             }
         });
-        pass(eb, npb, std::integral_constant<int, S_K1>(), rc.z, rc.w, S_ + n0_, S_ + n0_ + n1_, pb_, [&](auto) {});
+        pass(eb, npb, more ? gnb : 0, std::integral_constant<int, S_K1>(), rc.z, rc.w, S_ + n0_, S_ + n0_ + n1_, pb_, [&](auto) {});
         SK_TICK(2)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next image and the next entries have landed
         rc = rn; hc = hn; hn = h2;

@@ -29,7 +29,7 @@ def timed(fn, reps=10):
 
 
 ABL = ((0, "full"), (1, "no walk (loads + staging + barriers)"), (2, "no staging"))
-ROLES = (("16 wavefronts", 0, 16, ["wait for the prefetch to land", "wait at the barrier", "walk", "top of the block"]),)
+ROLES = (("8 walking wavefronts", 0, 8, ["wait for the prefetch to land", "wait at the barrier", "walk", "top of the block"]),)
 for tr in ((False, True) if both else (False,)):
     n_in, n_out = (b.M, b.N) if tr else (b.N, b.M)
     H = torch.randn(n_in, 16, device="cuda")
@@ -40,7 +40,7 @@ for tr in ((False, True) if both else (False,)):
     for abl, name in ABL:
         os.environ["MLLP_STREAM_ABLATION"] = str(abl)
         print(f"   {name:40s} {timed(lambda: b.spmm(H, transpose=tr, out=Y)):.3f} ms")
-    for stamp in (16, 28, 272, 284):
+    for stamp in (16, 28):
         os.environ["MLLP_STREAM_ABLATION"] = str(stamp)
         print(f"  -- stamps, ablation bits {stamp - 16} (4 = no LDS reads, 8 = no FMAs, 64 = no entry reloads, 256 = only wavefront 0 walks: its time = 16 x the walk figure)")
         for _ in range(2):

@@ -41,7 +41,16 @@ constexpr int SK_LDS = SK_YA + S_R * S_ROW_BYTES;
 constexpr int SK_PIECES = (S_CB * S_ROW_BYTES + 1023) / 1024; // LDS-DMA pieces of 1 KB per image
 constexpr int SK_NSTG = SK_STAGERS ? SK_STAGERS : S_NW;       // wavefronts that stage
 constexpr int SK_PPW = (SK_PIECES + SK_NSTG - 1) / SK_NSTG;   // pieces per staging wavefront
-constexpr int SK_D = 2;         // pipeline depth in steps: D + 1 sets of read results
+#ifndef MLLP_SK_D
+#define MLLP_SK_D 2
+#endif
+#ifndef MLLP_SK_SLEEP
+#define MLLP_SK_SLEEP 3
+#endif
+constexpr int SK_D = MLLP_SK_D; // pipeline depth in steps: D + 1 sets of read results
+constexpr int SK_NQ = (SK_D + 1) * S_RQ;        // register quads that the asm owns: D + 1 sets of S_RQ rows
+constexpr int SK_VGPRS = 168 - 4 * SK_NQ;       // what is left for the compiler
+static_assert(SK_NQ <= 16, "SK_QUADS names 16 quads");
 static_assert(SK_LDS + 256 <= 163840 && SK_THREADS <= 1024, "one CU");
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -79,12 +88,47 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
-// An asm read's destination is written when the data returns, long after the statement: every consumer is made
-// data-dependent on the matching counted wait ("+v" tie behind it), and no asm read is left without one.
-__device__ __forceinline__ f32x4s lds_read16(unsigned addr) {
-    f32x4s v;
-    asm volatile("ds_read_b128 %0, %1" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
+// The walk's LDS reads land in FIXED registers that the compiler never sees: the kernel is compiled for
+// 168 - 4 SK_NQ VGPRs (amdgpu_num_vgpr) and the quads above that are named in the asm text, written by ds_read_b128 and
+// read by v_pk_fma_f32 / v_pk_add_f32, all inline asm, ordered by `volatile` and by the counted waits between them.
+// (An asm read's destination is written when the data returns, long after the statement.  With compiler-allocated
+// destinations hipcc copied such values at control-flow joins before the wait -- stale data, and the late write then
+// landed in a register it had reused: wrong results and a memory fault, profiles/r03_stream_experiments.txt.)
+// Quad I = v[164 - 4 I : 167 - 4 I].
+#define SK_QUADS(F)                                                                                                   \
+    F(0, "164", "165", "166", "167") F(1, "160", "161", "162", "163") F(2, "156", "157", "158", "159")                 \
+    F(3, "152", "153", "154", "155") F(4, "148", "149", "150", "151") F(5, "144", "145", "146", "147")                 \
+    F(6, "140", "141", "142", "143") F(7, "136", "137", "138", "139") F(8, "132", "133", "134", "135")                 \
+    F(9, "128", "129", "130", "131") F(10, "124", "125", "126", "127") F(11, "120", "121", "122", "123")               \
+    F(12, "116", "117", "118", "119") F(13, "112", "113", "114", "115") F(14, "108", "109", "110", "111")              \
+    F(15, "104", "105", "106", "107")
+template <int I>
+__device__ __forceinline__ void xq_read(unsigned addr) {
+#define SK_F(N, A, B, C, D)                                                                                           \
+    if constexpr (I == N)                                                                                             \
+        asm volatile("ds_read_b128 v[" A ":" D "], %0" : : "v"(addr) : "memory", "v" A, "v" B, "v" C, "v" D);
+    SK_QUADS(SK_F)
+#undef SK_F
+}
+// lo += v * quad.xy, hi += v * quad.zw (v = low half of vv)
+template <int I>
+__device__ __forceinline__ void xq_fma(f32x2s vv, f32x2s& lo, f32x2s& hi) {
+#define SK_F(N, A, B, C, D)                                                                                           \
+    if constexpr (I == N)                                                                                             \
+        asm volatile("v_pk_fma_f32 %0, %2, v[" A ":" B "], %0 op_sel_hi:[0,1,1]\n\t"                                  \
+                     "v_pk_fma_f32 %1, %2, v[" C ":" D "], %1 op_sel_hi:[0,1,1]"                                      \
+                     : "+v"(lo), "+v"(hi) : "v"(vv) : "v" A, "v" B, "v" C, "v" D);
+    SK_QUADS(SK_F)
+#undef SK_F
+}
+template <int I>
+__device__ __forceinline__ void xq_add(f32x2s& lo, f32x2s& hi) {
+#define SK_F(N, A, B, C, D)                                                                                           \
+    if constexpr (I == N)                                                                                             \
+        asm volatile("v_pk_add_f32 %0, %0, v[" A ":" B "]\n\tv_pk_add_f32 %1, %1, v[" C ":" D "]"                      \
+                     : "+v"(lo), "+v"(hi) : : "v" A, "v" B, "v" C, "v" D);
+    SK_QUADS(SK_F)
+#undef SK_F
 }
 // one 4-byte LDS write (a lane's own word of a dummy region) that only keeps the count of outstanding LDS operations
 // uniform.  A write, not a read: nothing would keep the compiler from reusing a dummy read's destination register
@@ -96,7 +140,6 @@ template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
 }
-__device__ __forceinline__ void lds_tie(f32x4s& a) { asm volatile("" : "+v"(a) : : "memory"); }
 
 // Static sites of a pass (compile-time recursion: the register sets must be indexed by constants): site S issues the
 // reads of step S, does the FMAs of step S - D behind a wait for "at most S_RQ D LDS operations outstanding", and calls
@@ -110,10 +153,11 @@ template <int S, int K, class FI, class FP, class FF, class FH>
 __device__ __forceinline__ void stream_sites(int ra, int rb, FI&& issue_s, FP&& pad_s, FF&& fma_s, FH&& hook) {
     if constexpr (S < S_GS * K + SK_D) {
         if (S >= ra && S < rb + SK_D) {                                  // wave-uniform
-            if (S < rb) {
-                if constexpr (S < S_GS * K) issue_s(std::integral_constant<int, S>());
+            if constexpr (S < S_GS * K) {
+                if (S < rb) issue_s(std::integral_constant<int, S>());
+                else pad_s();
             } else {
-                pad_s();
+                pad_s();        // (steps behind the register set are walked by the slow path, not pipelined)
             }
             if constexpr (S >= SK_D) {
                 if (S - SK_D >= ra) fma_s(std::integral_constant<int, S - SK_D>());
@@ -127,7 +171,7 @@ __device__ __forceinline__ void stream_sites(int ra, int rb, FI&& issue_s, FP&& 
 // ABL (timing build only): 1 = no walk, 2 = no staging, 4 = no LDS reads, 8 = no FMAs, 16 = cycle stamps instead of the
 // result, 64 = no entry reloads
 template <int ABL>
-__global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, const float* __restrict__ X,
+__global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS))) void spmm_stream_kernel(StreamDev t, const float* __restrict__ X,
                                                                  float* __restrict__ Y) {
     __shared__ __attribute__((aligned(16))) char smem[SK_LDS + 256];     // + a dummy word per lane (lds_pad)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(src + piece * 1024),
                         (__attribute__((address_space(3))) void*)(img_base + piece * 1024), 16, 0, 0);
-                if (paced) __builtin_amdgcn_s_sleep(3);      // a burst would block the walkers in their own loads
+                if (paced) __builtin_amdgcn_s_sleep(MLLP_SK_SLEEP);      // a burst would block the walkers in their own loads
             }
         };
         stage(0, 0, false);
@@ -242,32 +286,30 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
         int ri[S_RQ];
 #pragma unroll
         for (int r = 0; r < S_RQ; ++r) ri[r] = ((((r & 2) ? r23 : r01) >> (16 * (r & 1))) & 0xffff) * 4 + part;
-        f32x4s y[S_RQ];
+        // accumulators of the rows: ordinary (compiler-managed) reads in front of the first site -- the asm statements
+        // are memory barriers for the compiler, so they are issued here -- added behind the last step
+        float4 y[S_RQ];
 #pragma unroll
-        for (int r = 0; r < S_RQ; ++r) y[r] = lds_read16(SK_YA + ri[r] * 16);
+        for (int r = 0; r < S_RQ; ++r) y[r] = Ya[ri[r]];
         f32x2s acc[2 * S_RQ];
 #pragma unroll
         for (int r = 0; r < 2 * S_RQ; ++r) acc[r] = f32x2s{0.f, 0.f};
         const int ra = a % S_GS, rb = b - (a - ra);
         const unsigned pad_addr = (unsigned)(SK_LDS + lane * 4);
-        f32x4s x[SK_D + 1][S_RQ];
         stream_sites<0, K>(
             ra, rb,
             [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int l0 = ((s % S_GS) >> 1) * S_RQ;        // lane (of the quad) that holds slot 0 of step s
+                constexpr int q0 = (s % (SK_D + 1)) * S_RQ;         // first register quad of the step's read set
                 // this lane's offset of step s (meaningful in the lanes that hold step s: part / S_RQ == (s % S_GS) / 2)
                 const int o = (s & 1) ? (int)((unsigned)cur[s / S_GS].o >> 16) : (cur[s / S_GS].o & 0xffff);
-                if (ABL & 4) {
-#pragma unroll
-                    for (int r = 0; r < S_RQ; ++r) x[s % (SK_D + 1)][r] = f32x4s{1.f, 1.f, 1.f, (float)o};
-                    return;
-                }
-                x[s % (SK_D + 1)][0] = lds_read16(pb + qbcast<l0>(o));
-                x[s % (SK_D + 1)][1] = lds_read16(pb + qbcast<l0 + 1>(o));
+                if (ABL & 4) return;
+                xq_read<q0>(pb + qbcast<l0>(o));
+                xq_read<q0 + 1>(pb + qbcast<l0 + 1>(o));
                 if constexpr (S_RQ == 4) {
-                    x[s % (SK_D + 1)][2] = lds_read16(pb + qbcast<(l0 + 2) & 3>(o));
-                    x[s % (SK_D + 1)][3] = lds_read16(pb + qbcast<(l0 + 3) & 3>(o));
+                    xq_read<q0 + 2>(pb + qbcast<(l0 + 2) & 3>(o));
+                    xq_read<q0 + 3>(pb + qbcast<(l0 + 3) & 3>(o));
                 }
             },
             [&]() {
@@ -278,22 +320,18 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
             [&](auto fc) {
                 constexpr int f = decltype(fc)::value;
                 constexpr int l0 = ((f % S_GS) >> 1) * S_RQ;
-                f32x4s(&xf)[S_RQ] = x[f % (SK_D + 1)];
-                if (!(ABL & 4)) {
-                    lds_wait<S_RQ * SK_D>();
-#pragma unroll
-                    for (int r = 0; r < S_RQ; ++r) lds_tie(xf[r]);
-                }
+                constexpr int q0 = (f % (SK_D + 1)) * S_RQ;
+                if (!(ABL & 4)) lds_wait<S_RQ * SK_D>();
                 const int v = (f & 1) ? cur[f / S_GS].v1 : cur[f / S_GS].v0;
                 if (ABL & 8) {
-                    acc[0].x += xf[0].x * __int_as_float(v) + xf[1].y;
+                    acc[0].x += __int_as_float(v);
                     return;
                 }
-                pk4(__int_as_float(qbcast<l0>(v)), xf[0], acc[0], acc[1]);
-                pk4(__int_as_float(qbcast<l0 + 1>(v)), xf[1], acc[2], acc[3]);
+                xq_fma<q0>(f32x2s{__int_as_float(qbcast<l0>(v)), 0.f}, acc[0], acc[1]);
+                xq_fma<q0 + 1>(f32x2s{__int_as_float(qbcast<l0 + 1>(v)), 0.f}, acc[2], acc[3]);
                 if constexpr (S_RQ == 4) {
-                    pk4(__int_as_float(qbcast<(l0 + 2) & 3>(v)), xf[2], acc[4], acc[5]);
-                    pk4(__int_as_float(qbcast<(l0 + 3) & 3>(v)), xf[3], acc[6], acc[7]);
+                    xq_fma<q0 + 2>(f32x2s{__int_as_float(qbcast<(l0 + 2) & 3>(v)), 0.f}, acc[4], acc[5]);
+                    xq_fma<q0 + 3>(f32x2s{__int_as_float(qbcast<(l0 + 3) & 3>(v)), 0.f}, acc[6], acc[7]);
                 }
             },
             [&](auto hc_) {
@@ -306,6 +344,7 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
                 }
                 extra(hc_);
             });
+        lds_wait<0>();      // nothing is in flight into the asm's registers from here on
         for (int st = S_GS * K; st < rb; ++st) {
             const Ent3 e = ld3(t.ent + (size_t)(a / S_GS + st / S_GS) * 64 + lane);
             const int o = (st & 1) ? (int)((unsigned)e.o >> 16) : (e.o & 0xffff), v = (st & 1) ? e.v1 : e.v0;
@@ -317,14 +356,9 @@ __global__ __launch_bounds__(SK_THREADS) void spmm_stream_kernel(StreamDev t, co
                 pk4(__int_as_float(__shfl(v, src, 64)), xs, acc[2 * r], acc[2 * r + 1]);
             }
         }
-        lds_wait<0>();
 #pragma unroll
-        for (int r = 0; r < S_RQ; ++r) {
-            lds_tie(y[r]);
-            acc[2 * r] += f32x2s{y[r].x, y[r].y};
-            acc[2 * r + 1] += f32x2s{y[r].z, y[r].w};
-            Ya[ri[r]] = make_float4(acc[2 * r].x, acc[2 * r].y, acc[2 * r + 1].x, acc[2 * r + 1].y);
-        }
+        for (int r = 0; r < S_RQ; ++r)
+            Ya[ri[r]] = make_float4(acc[2 * r].x + y[r].x, acc[2 * r].y + y[r].y, acc[2 * r + 1].x + y[r].z, acc[2 * r + 1].y + y[r].w);
     };
     SK_TICK(0)
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): image 0 and the first entries have landed
@@ -398,7 +432,7 @@ int launch_spmm_stream(const StreamCopy& sc, int n_dst, int n_src, const float* 
     if (const char* e = getenv("MLLP_STREAM_ABLATION")) abl = atoi(e);
 #define SK_LAUNCH(A) \
     if (abl == A) hipLaunchKernelGGL(spmm_stream_kernel<A>, dim3(sc.n_tiles), dim3(SK_THREADS), 0, s, t, H, Y);
-    SK_LAUNCH(1) SK_LAUNCH(2) SK_LAUNCH(3) SK_LAUNCH(4) SK_LAUNCH(8) SK_LAUNCH(12) SK_LAUNCH(16) SK_LAUNCH(28) SK_LAUNCH(80) SK_LAUNCH(272) SK_LAUNCH(284)
+    SK_LAUNCH(1) SK_LAUNCH(2) SK_LAUNCH(3) SK_LAUNCH(4) SK_LAUNCH(8) SK_LAUNCH(12) SK_LAUNCH(16) SK_LAUNCH(18) SK_LAUNCH(28) SK_LAUNCH(80) SK_LAUNCH(272) SK_LAUNCH(284)
 #undef SK_LAUNCH
 #endif
     if (abl == 0) hipLaunchKernelGGL(spmm_stream_kernel<0>, dim3(sc.n_tiles), dim3(SK_THREADS), 0, s, t, H, Y);

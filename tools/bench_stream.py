@@ -6,6 +6,9 @@ import numpy as np
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("MLLP_LIB"):              # experiments: a variant build of the library
+    from mllp_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", os.environ["MLLP_LIB"])
 if os.environ.get("MLLP_TIMING_LIB"):
     from mllp_amd import _lib
     _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", "libmllp_hip_timing.so")

@@ -30,9 +30,9 @@ import os
 import sys
 import time
 
-# The library runs each step on two HIP streams; with RCCL's own streams in the process the default of 4 hardware
-# queues makes them share a queue and serialises the pair (measured 1.17 vs 0.98 ms/step).  The HIP runtime reads
-# this when it loads, i.e. at `import torch`.
+# Large batches run their step on two HIP streams (the latency-regime step is one stream); with RCCL's own streams in
+# the process the default of 4 hardware queues made the pair share a queue (measured 1.17 vs 0.98 ms/step in round 1).
+# The HIP runtime reads this when it loads, i.e. at `import torch`.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np   # noqa: E402
@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -60,7 +60,39 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads of the cpu_baseline leg")
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--hip-graph", default="auto", help="auto (capture only launch-bound batches) | True")
-    return ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the launch command as JSON and exit (no device touched)")
+    ap.add_argument("--master-port", type=int, default=29571)
+    return ap.parse_args(argv)
+
+
+def launch_command(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: the command that starts the N ranks (one process per
+    GPU, RCCL over xGMI; the parent never touches a device -- a process that has initialised the GPU must not be
+    replaced or forked on this pool).  `argv` is passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(args.master_port),
+            os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+
+
+def maybe_launch(args, argv):
+    """Returns an exit code if this process was only the launcher, None if it is a rank (or the single process)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={ws}", file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    cmd = launch_command(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "n_ranks": args.gpus}))
+        return 0
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.call(cmd, env=env)
 
 
 def timed(fn, reps, warm=2):
@@ -152,7 +184,11 @@ def cpu_baseline(instances, threads):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    rc = maybe_launch(args, argv)          # before anything touches a device
+    if rc is not None:
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,7 +249,9 @@ def main():
     value = head["value"]
     out = {
         "metric": "LP instances/sec (fwd+bwd) on Netlib batch; achieved HBM GB/s on CSR SpMM",
-        "value": value, "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "instances/s", "n_gpus": world,
+        "rccl_ranks": (__import__("torch.distributed").distributed.get_world_size() if dist_on else 1),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "Netlib LP (97 normalized instances packed in data/netlib_norm.npz); "
                                 "synthetic sparse LPs for the roofline section",

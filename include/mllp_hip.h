@@ -111,8 +111,8 @@ int mllp_spmm_csr_f32(const mllp_graph_t* g, int transpose, const float* d_H, fl
 int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const void* d_H_bf16, float* d_Y, void* stream);
 
 /* Streamed copy of one orientation for mllp_spmm_csr_f32 on large batches (rows of ~100+ nonzeros; layout and
- * rationale: mllp_amd/csrc/stream_layout.h).  The nonzeros are re-blocked ONCE into row tiles of at most 1024 rows (never
- * across two LP instances) x 625-column blocks and stored in the order the kernel's wavefronts consume them, so that they stream HBM -> registers while LDS
+ * rationale: mllp_amd/csrc/stream_layout.h).  The nonzeros are re-blocked ONCE into row tiles of at most 960 rows (never
+ * across two LP instances) x 750-column blocks and stored in the order the kernel's wavefronts consume them, so that they stream HBM -> registers while LDS
  * holds two images of H (double-buffered by LDS-DMA).  Replaces the edge list the reference rebuilds every step
  * (linear_program_methods.py:89-103).  The copy is LIBRARY-owned device memory (these three are not launch functions:
  * they allocate, free and synchronise), ~8.6 bytes per nonzero; mllp_spmm_csr_f32 uses it when present.

@@ -279,7 +279,7 @@ static void check_stream(std::mt19937& rng, int n_dst, int n_src, double mean_de
           a.n_groups == b.n_groups && a.tile_row == b.tile_row);
     CHECK((int)a.tile_row.size() == a.n_tiles + 1 && a.tile_row[0] == 0 && a.tile_row[a.n_tiles] == n_dst);
     for (int t = 0; t < a.n_tiles; ++t) {
-        CHECK(a.tile_row[t + 1] > a.tile_row[t] && a.tile_row[t + 1] - a.tile_row[t] <= S_R);
+        CHECK(a.tile_row[t + 1] > a.tile_row[t] && a.tile_row[t + 1] - a.tile_row[t] <= S_RR);
         for (int64_t sgm : seg) CHECK(!(sgm > a.tile_row[t] && sgm < a.tile_row[t + 1]));      // no tile crosses a segment
     }
     CHECK((int)a.tile_blk.size() == a.n_tiles + 1 && a.tile_blk[a.n_tiles] == a.n_tb);
@@ -369,7 +369,7 @@ int main(int argc, char** argv) {
         }
     }
     check_stream(rng, 2600, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 4 column blocks, a 1400-entry row
-    check_stream(rng, S_R, S_CB, 3.0, S_CB);       // exactly one tile, one block, one full row
+    check_stream(rng, S_RR, S_CB, 3.0, S_CB);      // exactly one tile, one block, one full row
     check_stream(rng, 40, 60, 2.0, 5);
     check_stream(rng, 1200, 4100, 40.0, 0);
     check_stream(rng, 3000, 1500, 9.0, 30, 4);     // four segments: ragged tiles at every segment end

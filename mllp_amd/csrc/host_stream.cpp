@@ -135,7 +135,7 @@ std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_
     const int64_t one[2] = {0, n_dst};
     if (!seg_ptr) { seg_ptr = one; n_seg = 1; }
     for (int64_t k = 0; k < n_seg; ++k)
-        for (int64_t r = seg_ptr[k]; r < seg_ptr[k + 1]; r += S_R) tr.push_back((int)std::min<int64_t>(r + S_R, seg_ptr[k + 1]));
+        for (int64_t r = seg_ptr[k]; r < seg_ptr[k + 1]; r += S_RR) tr.push_back((int)std::min<int64_t>(r + S_RR, seg_ptr[k + 1]));
     return tr;
 }
 

@@ -23,7 +23,7 @@ struct HostStream {
     std::vector<int> ent;            // [(n_groups + S_K0) * 64 * S_ENT]
 };
 
-// Row tiles of at most S_R rows that never cross a segment boundary (seg_ptr: [n_seg + 1] ascending row offsets of the
+// Row tiles of at most S_RR rows that never cross a segment boundary (seg_ptr: [n_seg + 1] ascending row offsets of the
 // LP instances, first 0, last n_dst; null = one segment).
 std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst);
 

@@ -25,6 +25,9 @@
 // entry of each of the quad's rows for each of the 16 quads; the pass takes n = (entries of the bundle's longest
 // row) steps, shorter rows are padded with entries {zero row, 0.0f} that read the all-zero row behind the image
 // (4 % of the slots on the synthetic batch).
+// Tiles hold at most S_RR = 960 rows: the missing rows sort last and form the empty bundle 15, so wavefront 0, whose
+// bundle 0 holds the rows of the long tail, has no second pass.  With 1024 rows its two passes took 1.38 x the steps of
+// the average wavefront and everybody waited for it at the barrier of every block; with 960 it is 1.16 x.
 // (Why 16 wavefronts of little work each: a wavefront issues about one instruction per 4-5 cycles whatever the
 // instruction is; with 8 walking wavefronts, 4 rows per quad, the walk of a block took ~5 000 cycles of which the LDS
 // reads and the FMAs together accounted for 900 -- profiles/r03_stream_experiments.txt.)
@@ -51,15 +54,16 @@
 
 namespace mllp {
 
-constexpr int S_R = 1024;                   // rows per tile (at most)
-constexpr int S_CB = 625;                   // source nodes per column block
+constexpr int S_R = 1024;                   // row slots per tile
+constexpr int S_RR = S_R - 64;              // rows per tile (at most): the last bundle stays empty, see below
+constexpr int S_CB = 750;                   // source nodes per column block
 constexpr int S_NW = 8;                     // walking wavefronts per workgroup
 constexpr int S_RQ = 4;                     // rows per quad and pass
 constexpr int S_GS = 8 / S_RQ;              // steps per group
 constexpr int S_BR = 16 * S_RQ;             // rows per bundle
 constexpr int S_NB = S_R / S_BR;            // bundles of sorted positions
 constexpr int S_P = S_NB / S_NW;            // passes per wavefront and block
-constexpr int S_K0 = 9, S_K1 = 4;           // groups of pass 0 / pass 1 that a wavefront holds in registers
+constexpr int S_K0 = 12, S_K1 = 4;          // groups of pass 0 / pass 1 that a wavefront holds in registers
 constexpr int S_ENT = 3;                    // int32 per (group, lane)
 constexpr int S_ROW_BYTES = 64;             // one fp32 feature row
 constexpr int S_ZERO_OFF = S_CB * S_ROW_BYTES;   // byte offset of the all-zero row behind the image

@@ -11,11 +11,11 @@
 //              quad by DPP, one ds_read_b128 of the source row per entry, two packed FMAs per lane.  The steps are
 //              static code, software-pipelined by hand (the reads of step s + SK_D are issued before the FMAs of step
 //              s); the rows' accumulators are read from LDS at the start of a pass and written back at its end.
-//   staging    its share (3 pieces of 1 KB) of the NEXT block's 625 x 64 B of H by LDS-DMA (global_load_lds_dwordx4: no
+//   staging    the NEXT block's 750 x 64 B of H by LDS-DMA (global_load_lds_dwordx4: no
 //              registers, no ds_write) into the image that is not being read, one piece per site.
 //   barrier    one per block: behind it image b + 1 and everybody's entries of block b + 1 have landed (vmcnt(0) on
 //              every wavefront, MI355X_MICROARCH.md "Two waves per SIMD" item 7) and the reads of image b are done.
-//   LDS        image 0 | image 1 (40 000 B + one all-zero row each) | accumulators of the tile (64 KB) | dummy words.
+//   LDS        image 0 | image 1 (48 000 B + one all-zero row each) | accumulators of the tile (64 KB) | dummy words.
 // Three things are done by hand because hipcc's s_waitcnt insertion cannot see through them
 // (profiles/r03_stream_experiments.txt):
 //   * the LDS-DMA is issued from inline asm: behind a visible global_load_lds every LDS read waits for vmcnt(0) (the
@@ -42,7 +42,7 @@ constexpr int SK_PIECES = (S_CB * S_ROW_BYTES + 1023) / 1024; // LDS-DMA pieces 
 constexpr int SK_NSTG = SK_STAGERS ? SK_STAGERS : S_NW;       // wavefronts that stage
 constexpr int SK_PPW = (SK_PIECES + SK_NSTG - 1) / SK_NSTG;   // pieces per staging wavefront
 #ifndef MLLP_SK_D
-#define MLLP_SK_D 2
+#define MLLP_SK_D 1
 #endif
 #ifndef MLLP_SK_SLEEP
 #define MLLP_SK_SLEEP 3
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS
     if (!SK_STAGERS)
         for (int i = 0; i < SK_PPW; ++i) stage_piece(hc.z, 0, i);
 
-    Ent3 ea[S_K0], eb[S_K1];
+    Ent3 ea[S_K0], eb[S_K1], eb2[S_K1];     // pass 1 has two sets: the next block's is loaded during pass 0 (see `block`)
     auto ld3 = [&](const Ent3* p) {
         Ent3 e;
         e.o = __builtin_nontemporal_load(&p->o);
@@ -364,7 +364,10 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): image 0 and the first entries have landed
     __syncthreads();
     SK_TICK(1)
-    for (int k = 0; k < nb; ++k) {
+    // One block.  The pass-0 set `ea` is reloaded in place (group j behind its last step); the pass-1 set of the NEXT
+    // block goes into the other of eb / eb2 during pass 0: reloaded in place, its loads would be the last ones of the
+    // block and every wavefront stood ~700 cycles per block at the barrier waiting for them to land.
+    auto block = [&](int k, auto& ebc, auto& ebn) {
         // rows of the next block, header of the one after it (the walk below needs the next header's addresses)
         const i32x4 rn = __builtin_nontemporal_load(rowp + 16 * S_NW * min(k + 1, nb - 1));
         const i32x4 h2 = hdrp[S_NW * min(k + 2, nb - 1)];
@@ -372,28 +375,37 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS
         const Ent3* npb = set_base(hn, 1);
         const int nS_ = __builtin_amdgcn_readfirstlane(hn.x);
         const unsigned nc_ = (unsigned)__builtin_amdgcn_readfirstlane(hn.y);
-        const int gna = (nS_ % S_GS + (int)(nc_ & 0xffffu) + S_GS - 1) / S_GS;            // groups the next block's passes use
-        const int gnb = ((nS_ + (int)(nc_ & 0xffffu)) % S_GS + (int)(nc_ >> 16) + S_GS - 1) / S_GS;
         const bool more = k + 1 < nb;
+        // groups the next block's passes use
+        const int gna = more ? (nS_ % S_GS + (int)(nc_ & 0xffffu) + S_GS - 1) / S_GS : 0;
+        const int gnb = more ? ((nS_ + (int)(nc_ & 0xffffu)) % S_GS + (int)(nc_ >> 16) + S_GS - 1) / S_GS : 0;
         const int nblk = hn.z, nimg = (k + 1) & 1;
         SK_TICK(3)
         const int S_ = __builtin_amdgcn_readfirstlane(hc.x);
         const unsigned c_ = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
         const int n0_ = (int)(c_ & 0xffffu), n1_ = (int)(c_ >> 16);
         const unsigned pb_ = (unsigned)((k & 1) * SK_IMG + part * 16);
-        pass(ea, npa, more ? gna : 0, std::integral_constant<int, S_K0>(), rc.x, rc.y, S_, S_ + n0_, pb_, [&](auto sc) {
-            constexpr int s = decltype(sc)::value;          // the LDS-DMA pieces of the next image, one per site
-            if constexpr (!SK_STAGERS && s % 3 == 1 && s / 3 < SK_PPW) {
+        pass(ea, npa, gna, std::integral_constant<int, S_K0>(), rc.x, rc.y, S_, S_ + n0_, pb_, [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s % 2 == 0 && s / 2 < S_K1) {     // the next block's pass-1 entries, one group per even site
+                if (s / 2 < gnb && !(ABL & 64)) ebn[s / 2] = ld3(npb + 64 * (s / 2));
+            }
+            if constexpr (!SK_STAGERS && s % 3 == 1 && s / 3 < SK_PPW) {    // the LDS-DMA pieces of the next image
                 if (more) stage_piece(nblk, nimg, s / 3);
             }
         });
-        pass(eb, npb, more ? gnb : 0, std::integral_constant<int, S_K1>(), rc.z, rc.w, S_ + n0_, S_ + n0_ + n1_, pb_, [&](auto) {});
+        pass(ebc, npb, 0, std::integral_constant<int, S_K1>(), rc.z, rc.w, S_ + n0_, S_ + n0_ + n1_, pb_, [&](auto) {});
         SK_TICK(2)
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next image and the next entries have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next entries (and, when this wavefront stages, the image) have landed
         rc = rn; hc = hn; hn = h2;
         SK_TICK(0)
         __syncthreads();
         SK_TICK(1)
+    };
+    for (int k = 0; k < nb; k += 2) {
+        block(k, eb, eb2);
+        if (k + 1 >= nb) break;
+        block(k + 1, eb2, eb);
     }
     if (ABL & 16) {
         // stamps instead of the result, summed over the wavefronts: row 2 * tile = {[0] wait for the prefetch to land,

@@ -134,8 +134,11 @@ std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_
     std::vector<int> tr(1, 0);
     const int64_t one[2] = {0, n_dst};
     if (!seg_ptr) { seg_ptr = one; n_seg = 1; }
-    for (int64_t k = 0; k < n_seg; ++k)
-        for (int64_t r = seg_ptr[k]; r < seg_ptr[k + 1]; r += S_RR) tr.push_back((int)std::min<int64_t>(r + S_RR, seg_ptr[k + 1]));
+    for (int64_t k = 0; k < n_seg; ++k) {
+        // equal tiles inside a segment (10 000 rows = 11 x 909-910, not 10 x 960 + 400): workgroups of equal duration
+        const int64_t len = seg_ptr[k + 1] - seg_ptr[k], nt = (len + S_RR - 1) / S_RR;
+        for (int64_t i = 1; i <= nt; ++i) tr.push_back((int)(seg_ptr[k] + len * i / nt));
+    }
     return tr;
 }
 

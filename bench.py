@@ -296,18 +296,31 @@ def main():
         Ym = torch.empty(sb.M, 16, device="cuda")
         Yn = torch.empty(sb.N, 16, device="cuda")
         b_a, b_at = spmm_bytes(sb.nnz, sb.M, sb.N), spmm_bytes(sb.nnz, sb.N, sb.M)
-        # generic sweep (gathers from L2) first, then the LDS-tiled copy the library uses for large batches
+        # generic sweep (gathers from L2) first, then the streamed copy the library uses for large batches (built by HIP
+        # kernels, library-owned: mllp_graph_build_spmm_copy), then round 2's LDS-tiled kernel for comparison
         ms_ga = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps)
         ms_gat = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps)
-        ref_a = Ym.clone()
-        tiled_a, tiled_at = sb.enable_tiled(False), sb.enable_tiled(True)
-        ms_a = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps, warm=5) if tiled_a else ms_ga
-        ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps, warm=5) if tiled_at else ms_gat
-        tiled_err = float((Ym - ref_a).abs().max() / ref_a.abs().max())
+        ref_a, ref_at = Ym.clone(), Yn.clone()
+        info_a, info_at = sb.build_spmm_copy(False), sb.build_spmm_copy(True)
+        ms_a = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps, warm=5)
+        ms_at = timed(lambda: sb.spmm(Hm, transpose=True, out=Yn), args.spmm_reps, warm=5)
+        err_a = float((Ym - ref_a).abs().max() / ref_a.abs().max())
+        err_at = float((Yn - ref_at).abs().max() / ref_at.abs().max())
         gbs_a, gbs_at = b_a / ms_a / 1e6, b_at / ms_at / 1e6
-        # opt-in bf16 feature image of the same kernel (NOT the parity path; printed beside the fp32 line, never as it)
-        bf16_line = None
+        sb.drop_spmm_copy(False)
+        sb.drop_spmm_copy(True)
+        # round 2's kernel (LDS-tiled copy, variant 0, built with torch ops) and its opt-in bf16 feature image (NOT the
+        # parity path; printed beside the fp32 lines, never as them)
+        t_v0 = time.perf_counter()
+        tiled_a = sb.enable_tiled(False)
+        torch.cuda.synchronize()
+        t_v0 = time.perf_counter() - t_v0
+        r02_line = bf16_line = None
         if tiled_a:
+            ms_r02 = timed(lambda: sb.spmm(Hn, out=Ym), args.spmm_reps, warm=5)
+            r02_line = {"kernel": "spmm_tiled_ws_kernel A*H (round 2: 512 x 1024 LDS-tiled copy, entries staged in LDS)",
+                        "ms": ms_r02, "alg_bytes": b_a, "GBps": b_a / ms_r02 / 1e6, "frac": b_a / ms_r02 / 1e6 / HBM_PEAK_GBS,
+                        "copy_build_s (torch ops)": t_v0}
             Hb = Hn.to(torch.bfloat16).contiguous()
             ms_b = timed(lambda: sb.spmm_bf16(Hb, out=Ym), args.spmm_reps, warm=5)
             b_b = b_a - sb.N * 32                                   # source rows are 32 bytes instead of 64
@@ -315,17 +328,23 @@ def main():
                          "alg_bytes": b_b, "GBps": b_b / ms_b / 1e6, "frac": b_b / ms_b / 1e6 / HBM_PEAK_GBS,
                          "max_rel_diff_vs_fp32": float((Ym - ref_a).abs().max() / ref_a.abs().max())}
             del Hb
+            sb.disable_tiled(False)
         kernels = [
-            {"kernel": "spmm_tiled A*H", "ms": ms_a, "alg_bytes": b_a, "GBps": gbs_a, "frac": gbs_a / HBM_PEAK_GBS,
-             "max_rel_diff_vs_generic": tiled_err},
-            {"kernel": "spmm_tiled At*H", "ms": ms_at, "alg_bytes": b_at, "GBps": gbs_at, "frac": gbs_at / HBM_PEAK_GBS},
-        ] + ([bf16_line] if bf16_line else []) + [
+            {"kernel": "spmm_stream_kernel A*H", "ms": ms_a, "alg_bytes": b_a, "GBps": gbs_a, "frac": gbs_a / HBM_PEAK_GBS,
+             "max_rel_diff_vs_generic": err_a, "copy_bytes": info_a["bytes"], "entry_slots_per_nnz": info_a["entry_slots"] / sb.nnz,
+             "copy_build_s": info_a["build_us"] / 1e6},
+            {"kernel": "spmm_stream_kernel At*H", "ms": ms_at, "alg_bytes": b_at, "GBps": gbs_at, "frac": gbs_at / HBM_PEAK_GBS,
+             "max_rel_diff_vs_generic": err_at, "copy_bytes": info_at["bytes"],
+             "entry_slots_per_nnz": info_at["entry_slots"] / sb.nnz, "copy_build_s": info_at["build_us"] / 1e6},
+        ] + ([r02_line] if r02_line else []) + ([bf16_line] if bf16_line else []) + [
             {"kernel": "sweep_kernel<SpmmOp> A*H (generic, L2 gathers)", "ms": ms_ga, "alg_bytes": b_a,
              "GBps": b_a / ms_ga / 1e6, "frac": b_a / ms_ga / 1e6 / HBM_PEAK_GBS},
             {"kernel": "sweep_kernel<SpmmOp> At*H (generic, L2 gathers)", "ms": ms_gat, "alg_bytes": b_at,
              "GBps": b_at / ms_gat / 1e6, "frac": b_at / ms_gat / 1e6 / HBM_PEAK_GBS},
         ]
-        del Ym, Yn, ref_a
+        del Ym, Yn, ref_a, ref_at
+        sb.tiled_build_s = 0.0                       # from here on: the copies of the training step
+        lg_generic = sb.loss_step(params0, 1.0 / sb.n_inst)[1].clone()      # whole model on the generic sweeps, full size
         # one attention conv forward (16-wide), destination = constraints: generic sweep, then the LDS-tiled one
         cp = params0[1392:1392 + 1104].contiguous()
         ws = sb.tconv_workspace(False, 16)
@@ -382,17 +401,25 @@ def main():
                             "ms": ms_1t, "alg_bytes": b_f1, "GBps": b_f1 / ms_1t / 1e6,
                             "frac": b_f1 / ms_1t / 1e6 / HBM_PEAK_GBS})
         del ws1, x1s, x1d
-        out["roofline"] = {"bound": "hbm", "kernel": "spmm_tiled_kernel (plain CSR SpMM, Y = A*H, C=16, fp32, LDS-tiled)",
+        out["roofline"] = {"bound": "hbm", "kernel": "spmm_stream_kernel (plain CSR SpMM, Y = A*H, C=16, fp32, streamed copy: "
+                                                     "entries HBM -> registers, H double-buffered in LDS by LDS-DMA)",
                            "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
-                                       f"nnz={sb.nnz}", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       f"nnz={sb.nnz}; geometric-gap generator (graph.py::synthetic_batch), seed 1234 + "
+                                       "first instance of each 16-instance chunk", "achieved": gbs_a, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s",
                            "frac": gbs_a / HBM_PEAK_GBS, "alg_bytes_per_launch": b_a, "ms_per_launch": ms_a,
-                           "traffic": load_traffic("spmm_tiled"),
+                           "traffic": load_traffic("spmm_stream"),
                            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc passes, gfx950-"
                                              "corrected; precomputed, not measured by this run)",
                            "kernels": kernels}
         del Hn
-        # full training step on the synthetic batch
+        # full training step on the synthetic batch with every tiled copy of the attention sweeps attached; its logits
+        # against those of the generic sweeps at the same full size (taken above, before any copy was attached)
         tr = LPTrainer(params0, lr=1e-3, use_hip_graph=False, global_instances=sb.n_inst * world)
+        tr._plan(sb)                                   # (the tiled copies of the attention sweeps were attached above)
+        lg_tiled = sb.loss_step(params0, 1.0 / sb.n_inst)[1]
+        logits_diff = float((lg_tiled - lg_generic).abs().max() / lg_generic.abs().max())
+        del lg_generic, lg_tiled
         for _ in range(2):
             tr.step(sb)
         barrier_sync(dist_on)
@@ -405,7 +432,10 @@ def main():
                             "instances_per_gpu": sb.n_inst, "nnz_per_gpu": sb.nnz, "steps": args.synthetic_steps,
                             "ms_per_step": 1e3 * dts / args.synthetic_steps,
                             "value": sb.n_inst * world * args.synthetic_steps / dts, "unit": "instances/s",
-                            "generate_s": t_gen}
+                            "generate_s": t_gen, "graph_build_s": t_gen,
+                            "tiled_build_s": getattr(sb, "tiled_build_s", None),
+                            "tiled_build": "8 LDS-tiled copies of the attention sweeps (variants 1-4 x 2 orientations), torch ops",
+                            "logits_max_rel_diff_tiled_vs_generic": logits_diff}
         # configs[4] as STRONG scaling: one Adam step per 2048 instances = 8 / N micro-batches of 256 per rank, gradients
         # accumulated, one all-reduce.  The micro-batches reuse the resident synthetic batch (same work per launch;
         # 8 distinct 256-instance batches with their tiled copies do not fit in 288 GB).

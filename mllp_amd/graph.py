@@ -266,9 +266,14 @@ class LPBatch:
         R, CB, CAP = c_int32(), c_int32(), c_int32()
         _lib.check(L.mllp_tiled_geometry(int(variant), ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
         R, CB, CAP = R.value, CB.value, CAP.value
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         ptr, idx, val = arrays if arrays is not None else self._device_orientation(transpose)
         n_dst = self.N if transpose else self.M
         built = build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant)
+        torch.cuda.synchronize()
+        self.tiled_build_s = getattr(self, "tiled_build_s", 0.0) + time.perf_counter() - t0   # seconds in the torch builder
         if built is None:
             return None
         keep, info = built
@@ -323,6 +328,12 @@ class LPBatch:
         """Attach every LDS-tiled copy (variants 0-4, both orientations): the throughput configuration for batches of
         hundreds of millions of nonzeros.  Costs ~8 bytes per nonzero and copy.  Returns {(transpose, variant): info}."""
         return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (0, 1, 2, 3, 4)}
+
+    def enable_tiled_step(self):
+        """The LDS-tiled copies that the TRAINING STEP uses (variants 1-4, both orientations): the attention sweeps.
+        Variant 0 belongs to the plain SpMM, which the step does not call (and which runs on the streamed copy,
+        `build_spmm_copy`).  `self.tiled_build_s` accumulates the seconds spent in the torch builder."""
+        return {(tr, v): self.enable_tiled(tr, variant=v) for tr in (False, True) for v in (1, 2, 3, 4)}
 
     def disable_tiled(self, transpose=False, variant=0):
         _lib.check(_lib.lib().mllp_graph_attach_tiled(self._h, int(transpose), int(variant), 0, 0, 0, c_void_p(0),

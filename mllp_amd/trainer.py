@@ -97,17 +97,17 @@ class DataParallelStep:
 
 
 class LPTrainer:
-    """HIP fast path: one `mllp_gnn_loss_step` + all-reduce + `mllp_adam_step` per batch, optionally
-    captured in hipGraphs (the Netlib batch is launch bound: ~30 small kernels per step)."""
+    """HIP fast path: one `mllp_gnn_loss_step` + all-reduce + `mllp_adam_step` per batch, launched eagerly on one
+    stream (the latency-regime step of the Netlib batch is 13 back-to-back launches), optionally captured in hipGraphs."""
 
-    # "auto": capture batches up to this many nonzeros.  0 = never: since the backward pass interleaves its convs on two
-    # streams, replaying the captured step is slower than launching it (single instances: 374-613 us vs 271-275 us eager;
-    # full Netlib batch 1.82 vs 0.94 ms; tools/graph_vs_eager.py) -- the runtime serialises the graph's branches.
-    # `use_hip_graph=True` still forces capture.
+    # "auto": capture batches up to this many nonzeros.  0 = never: the fused step's launches already run back to back,
+    # a single-stream capture replays within 1.5 % of eager (0.4755 vs 0.4687 ms, DESIGN.md section 2), and the
+    # per-instance loop is slower replayed (6.0 k vs 7.6 k instances/s).  `use_hip_graph=True` still forces capture.
     GRAPH_NNZ_LIMIT = 0
 
-    # "auto": batches of at least this many nonzeros get the LDS-tiled copies of both orientations (LPBatch.enable_tiled_all:
-    # the throughput regime of the library's row tiers starts at the same size); smaller ones use the generic sweeps
+    # "auto": batches of at least this many nonzeros get the LDS-tiled copies of the attention sweeps, both orientations
+    # (LPBatch.enable_tiled_step: the throughput regime of the library's row tiers starts at the same size); smaller ones
+    # run the fused latency-regime kernels
     TILED_NNZ_MIN = 32 << 20
 
     def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph="auto",
@@ -129,7 +129,7 @@ class LPTrainer:
             graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
             want_tiled = (batch.nnz >= self.TILED_NNZ_MIN) if self.tiled_copies == "auto" else bool(self.tiled_copies)
             if want_tiled and not getattr(batch, "_tiled", None):
-                batch.enable_tiled_all()
+                batch.enable_tiled_step()
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),
                      g_fwd=None, g_opt=None, warm=0, graph=graph)

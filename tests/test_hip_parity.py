@@ -667,8 +667,9 @@ def test_tiled_copies_edge_cases(LPBatch, weights):
 
 
 def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
-    """LPTrainer(tiled_copies=True) attaches every tiled copy on first use (the `auto` policy does the same for
-    batches of >= 32 M nonzeros) and trains like the generic path: losses of three Adam steps agree."""
+    """LPTrainer(tiled_copies=True) attaches the tiled copies of the training step on first use (variants 1-4: the
+    attention sweeps; the plain SpMM of variant 0 is not part of the step; the `auto` policy does the same for batches
+    of >= 32 M nonzeros) and trains like the generic path: losses of three Adam steps agree."""
     from mllp_amd.graph import synthetic_batch
     from mllp_amd.trainer import LPTrainer
     flat, sd, flat_gpu = weights
@@ -682,7 +683,8 @@ def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
             out.append(float(loss[0]))
         assert bool(getattr(sb, "_tiled", None)) == mode
         if mode:
-            assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (0, 1, 2, 3, 4)]
+            assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (1, 2, 3, 4)]
+            assert sb.tiled_build_s > 0
         losses[mode] = out
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-6, atol=0)
     auto = LPTrainer(flat_gpu, tiled_copies="auto")
@@ -691,9 +693,9 @@ def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
 
 def test_throughput_regime_32M_nonzeros(LPBatch, weights):
     """BASELINE.json configs[3] geometry at the size where the library changes regime (>= 32 M nonzeros: LPTrainer
-    attaches every LDS-tiled copy by itself, graph.cpp::choose_tiers switches to the throughput thresholds):
-    17 x (m = 10 000, n = 20 000).  Tiled vs generic for A H and A^T H, scipy on the exported CSR, the adjoint
-    identity <A x, y> = <x, A^T y>, and tiled vs generic logits / loss / gradients of the whole training step."""
+    attaches the LDS-tiled copies of the attention sweeps by itself, graph.cpp::choose_tiers switches to the throughput
+    thresholds): 17 x (m = 10 000, n = 20 000).  Streamed copy vs generic for A H and A^T H, scipy on the exported CSR,
+    the adjoint identity <A x, y> = <x, A^T y>, and tiled vs generic logits / loss / gradients of the whole training step."""
     import scipy.sparse as sp
     from mllp_amd.graph import synthetic_batch
     from mllp_amd.trainer import LPTrainer
@@ -709,10 +711,11 @@ def test_throughput_regime_32M_nonzeros(LPBatch, weights):
     close(Ya.cpu().numpy(), A @ Hn.double().cpu().numpy(), RTOL_ACT, "generic A H vs scipy at 34 M nnz")
     tr = LPTrainer(flat_gpu, lr=1e-3, tiled_copies="auto")
     loss1, logits1 = tr.step(sb)                                       # attaches the copies, then one fused step
-    assert sorted(sb._tiled) == [(t_, v) for t_ in (False, True) for v in (0, 1, 2, 3, 4)]
+    assert sorted(sb._tiled) == [(t_, v) for t_ in (False, True) for v in (1, 2, 3, 4)]
     close(logits1.cpu().numpy(), za.cpu().numpy(), RTOL_ACT, "trainer logits (tiled) vs generic")
     close(loss1.cpu().numpy(), la.cpu().numpy(), RTOL_ACT, "trainer loss (tiled) vs generic")
-    Yb, Ybt = sb.spmm(Hn), sb.spmm(Hm, transpose=True)                 # tiled
+    assert sb.build_spmm_copy(False)["n_tiles"] > 0 and sb.build_spmm_copy(True)["n_tiles"] > 0
+    Yb, Ybt = sb.spmm(Hn), sb.spmm(Hm, transpose=True)                 # streamed copy (library-owned, device builder)
     close(Yb.cpu().numpy(), Ya.cpu().numpy(), RTOL_ACT, "tiled A H vs generic")
     close(Ybt.cpu().numpy(), Yat.cpu().numpy(), RTOL_ACT, "tiled A^T H vs generic")
     close(Ybt.cpu().numpy(), A.T.tocsr() @ Hm.double().cpu().numpy(), RTOL_ACT, "tiled A^T H vs scipy")

@@ -96,6 +96,16 @@ int mllp_graph_export(const mllp_graph_t* g, int which, void* host_dst, int64_t 
  * Both paths compute the same quantities (tests compare them with each other and with the oracle).        */
 int mllp_graph_set_path(mllp_graph_t* g, int path);
 
+/* INPUT CONTRACT of the whole-model entry points on the fused path: the graph keeps renumbered copies of d_x1, d_x2
+ * and d_labels (and the layer-1 source features gathered beside the nonzeros), keyed on the POINTER VALUES -- the
+ * model's inputs are data (linear_program_methods.py:90-91), constant for the life of a batch.  A caller that changes
+ * their contents in place, or frees a buffer and gets the same address back for other data, must call
+ * mllp_graph_invalidate_inputs before the next mllp_gnn_* call on this graph (the generic / tiled path reads the
+ * pointers on every call and needs nothing).  Calls made while the stream is captured into a hipGraph re-make the
+ * copies inside the capture and leave the cache empty.  mllp_gnn_backward must follow an mllp_gnn_forward on the same
+ * workspace with the same path (MLLP_EINVAL otherwise: the two paths lay the workspace out differently).          */
+int mllp_graph_invalidate_inputs(mllp_graph_t* g);
+
 /* ------------------------------------------------------------------------------------------------
  * Plain CSR SpMM (the roofline kernel named in BASELINE.json's metric):
  *   transpose == 0:  Y[M,16] = A   * H[N,16]       transpose == 1:  Y[N,16] = A^T * H[M,16]

@@ -34,6 +34,7 @@ _PROTOTYPES = {
     "mllp_graph_dims": (c_int, [c_void_p, POINTER(c_int64)]),
     "mllp_graph_export": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
     "mllp_graph_set_path": (c_int, [c_void_p, c_int]),
+    "mllp_graph_invalidate_inputs": (c_int, [c_void_p]),
     "mllp_graph_build_spmm_copy": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "mllp_graph_drop_spmm_copy": (c_int, [c_void_p, c_int]),
     "mllp_graph_spmm_copy_info": (c_int, [c_void_p, c_int, POINTER(c_int64)]),

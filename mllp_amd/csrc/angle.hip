@@ -38,7 +38,12 @@ constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112, ROCBLAS_ATOMICS_NOT_ALLOWE
 const Blas& blas() {
     static Blas b = [] {
         Blas x;
-        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        // the copy that is already in the process first (torch loads its own under a versioned SONAME): two rocBLAS
+        // instances in one process would each keep their own kernels and handles
+        void* lib = nullptr;
+        for (const char* name : {"librocblas.so.5", "librocblas.so.4", "librocblas.so"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) return x;
         auto create = reinterpret_cast<int (*)(void**)>(dlsym(lib, "rocblas_create_handle"));

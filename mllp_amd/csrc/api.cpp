@@ -280,6 +280,12 @@ extern "C" int mllp_spmm_csr_bf16(const mllp_graph_t* g, int transpose, const vo
     return launch_spmm_tiled_bf16(o.tiled, o.n_dst, o.n_src, d_H_bf16, d_Y, (hipStream_t)stream);
 }
 
+extern "C" int mllp_graph_invalidate_inputs(mllp_graph_t* g) {
+    REQUIRE(g, "null graph");
+    g->bound_x1 = g->bound_x2 = g->bound_labels = nullptr;
+    return MLLP_OK;
+}
+
 extern "C" int mllp_graph_set_path(mllp_graph_t* g, int path) {
     REQUIRE(g, "null graph");
     REQUIRE(path >= 0 && path <= 2, "path must be 0 (by size), 1 (generic / LDS-tiled sweeps) or 2 (fused latency-regime kernels)");
@@ -365,8 +371,11 @@ extern "C" int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, co
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    mllp_graph* gm = const_cast<mllp_graph*>(g);          // (bookkeeping only: which path wrote which workspace)
+    gm->ws_ptr = d_ws;
+    gm->ws_path = use_fused(g) ? 1 : 0;
     if (use_fused(g))
-        return fused_forward(const_cast<mllp_graph*>(g), fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
+        return fused_forward(gm, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
     return launch_head(0, g->N, w.h3v, d_params + OFF_FC, d_params + OFF_FC + 16, g->inv_n, nullptr, 0.0f, nullptr,
                        d_logits, nullptr, w.head_partials, s);
@@ -378,8 +387,13 @@ extern "C" int mllp_gnn_backward(const mllp_graph_t* g, const float* d_params, c
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    // the two paths lay the workspace out differently (the fused one in renumbered node order): backward must follow
+    // a forward of the same path on the same workspace
+    REQUIRE(g->ws_ptr == d_ws && g->ws_path == (use_fused(g) ? 1 : 0),
+            "no mllp_gnn_forward on this workspace with the current path (mllp_graph_set_path between forward and backward?)");
     if (use_fused(g)) {      // (the node tensors of the fused path are in renumbered order: it has its own head kernel)
         const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, nullptr);
+        if ((rc = fused_bind(const_cast<mllp_graph*>(g), d_x1, d_x2, nullptr, s))) return rc;
         if ((rc = fused_head_backward(g, m, d_dlogits, s))) return rc;
         return fused_backward(g, m, false, d_grads, nullptr, s);
     }

@@ -1763,9 +1763,16 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
 }
 
 // renumbered copies of the inputs, made when the caller's pointers change (the contents are taken as constant while
-// the pointers are: the model's inputs are data -- reference linear_program_methods.py:90-91)
-static int fused_bind(mllp_graph* g, const float* x1, const float* x2, const float* labels, hipStream_t s) {
+// the pointers are: the model's inputs are data -- reference linear_program_methods.py:90-91; the contract and
+// mllp_graph_invalidate_inputs are in include/mllp_hip.h).  While the stream is being captured into a hipGraph the
+// copies are made inside the capture on every call and the cache is left empty: a captured launch has not run, so a
+// later eager call with the same pointers must not find the inputs "bound".
+int fused_bind(mllp_graph* g, const float* x1, const float* x2, const float* labels, hipStream_t s) {
     int rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (capturing) g->bound_x1 = g->bound_x2 = g->bound_labels = nullptr;
     if (x1 != g->bound_x1 || x2 != g->bound_x2) {
         if (g->N > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->N, g->perm_v, x1, g->x1_p);
         if (g->M > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->M, g->perm_c, x2, g->x2_p);
@@ -1777,12 +1784,12 @@ static int fused_bind(mllp_graph* g, const float* x1, const float* x2, const flo
                                reinterpret_cast<const int2*>(g->FAt.sent), g->x2_p, reinterpret_cast<float2*>(g->FAt.sax));
         }
         if ((rc = check_launch("fused_bind inputs"))) return rc;
-        g->bound_x1 = x1; g->bound_x2 = x2;
+        if (!capturing) { g->bound_x1 = x1; g->bound_x2 = x2; }
     }
     if (labels && labels != g->bound_labels) {
         if (g->N > 0) hipLaunchKernelGGL(fused_permute_kernel, dim3(256), dim3(256), 0, s, (int)g->N, g->perm_v, labels, g->labels_p);
         if ((rc = check_launch("fused_bind labels"))) return rc;
-        g->bound_labels = labels;
+        if (!capturing) g->bound_labels = labels;
     }
     return MLLP_OK;
 }

@@ -123,6 +123,8 @@ struct mllp_graph {
     const void* bound_x1 = nullptr;
     const void* bound_x2 = nullptr;
     const void* bound_labels = nullptr;
+    int ws_path = -1;            // which whole-model path wrote the workspace last: 0 generic / tiled, 1 fused (backward checks it)
+    const void* ws_ptr = nullptr;
     // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
     // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
     hipStream_t aux = nullptr;
@@ -243,6 +245,7 @@ struct FusedModel {
 };
 int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr);   // allocates: creation / set_path only
 int fused_grid(const mllp_graph* g);
+int fused_bind(mllp_graph* g, const float* x1, const float* x2, const float* labels, hipStream_t s);
 // head_mode 1: logits (h3v kept), 2: logits + BCE + masked dL/dh3v in d3v + fc partials
 int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s);
 // d3v = dlogits (original variable order) x fc weight in renumbered order, fc gradient partials

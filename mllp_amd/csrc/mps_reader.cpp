@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -63,10 +65,24 @@ bool to_double(const std::string& s, double* v) {
 
 }  // namespace
 
+static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out);
+
+// (no C++ exception may cross the C ABI: a malformed or huge file must come back as an error code)
 extern "C" int mllp_mps_read(const char* path, int normalize, mllp_lp_t** out) {
     using mllp::fail;
     if (!path || !out) return fail(MLLP_EINVAL, "mllp_mps_read: null argument");
     *out = nullptr;
+    try {
+        return mps_read_impl(path, normalize, out);
+    } catch (const std::bad_alloc&) {
+        return fail(MLLP_ENOMEM, std::string("mllp_mps_read: out of memory reading ") + path);
+    } catch (const std::exception& e) {
+        return fail(MLLP_EINVAL, std::string("mllp_mps_read: ") + e.what() + " (" + path + ")");
+    }
+}
+
+static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out) {
+    using mllp::fail;
     FILE* fh = std::fopen(path, "r");
     if (!fh) return fail(MLLP_EINVAL, std::string("mllp_mps_read: cannot open ") + path);
     std::vector<std::string> rows, cols;

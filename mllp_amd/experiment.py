@@ -172,6 +172,10 @@ def train_angle(cfg, method_name, train_dataset, train_dict, out=print):
     """reference linear_program_experiment.py:81-114: AngleModel(feat_dim=256) on the complete angle graph of the
     dense dataset's instance, BCEWithLogits + Adam, top-k metrics, train_log.json, state_dict .pt."""
     from .angle import AngleModel, get_netlib_dataloader
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # one instance, one dense graph: nothing to shard, and N ranks would all write the same files
+        raise RuntimeError("the angleNet method trains a single instance: run it with one rank")
     out(f"Training the model weights for {method_name}...")
     device = torch.device(cfg.get_default("device"))
     if device.type != "cuda" or not torch.cuda.is_available():

@@ -195,6 +195,22 @@ class LPBatch:
         if LPBatch.default_path:
             self.set_path(LPBatch.default_path)
 
+    def invalidate_inputs(self):
+        """x1 / x2 / labels were changed in place: the fused path re-makes its renumbered copies on the next call."""
+        _lib.check(_lib.lib().mllp_graph_invalidate_inputs(self._h))
+        self._in_versions = None
+        return self
+
+    def _check_inputs(self):
+        """torch counts in-place writes per tensor (`_version`): a change since the last whole-model call invalidates the
+        library's renumbered copies (include/mllp_hip.h, input contract), so `batch.x1.mul_(2)` just works."""
+        v = (self.x1._version, self.x2._version, self.labels._version, self.x1.data_ptr(), self.x2.data_ptr(),
+             self.labels.data_ptr())
+        if getattr(self, "_in_versions", None) != v:
+            if getattr(self, "_in_versions", None) is not None:
+                _lib.check(_lib.lib().mllp_graph_invalidate_inputs(self._h))
+            self._in_versions = v
+
     def set_path(self, path):
         """0 = by size, 1 = generic / LDS-tiled sweeps, 2 = fused latency-regime kernels (whole-model calls only)."""
         _lib.check(_lib.lib().mllp_graph_set_path(self._h, int(path)))
@@ -428,6 +444,7 @@ class LPBatch:
         assert params.is_cuda and params.dtype == torch.float32 and params.numel() == _lib.NUM_PARAMS
         if logits is None:
             logits = torch.empty(self.N, device=params.device, dtype=torch.float32)
+        self._check_inputs()
         _lib.check(_lib.lib().mllp_gnn_forward(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
                                                _lib.ptr(self.workspace()), _lib.ptr(logits), _lib.current_stream()))
         return logits
@@ -448,6 +465,7 @@ class LPBatch:
         loss = torch.empty(1, device=dev, dtype=torch.float32) if loss is None else loss
         grads = torch.empty(_lib.NUM_PARAMS, device=dev, dtype=torch.float32) if grads is None else grads
         ib = (1.0 / self.n_inst) if inv_batch is None else float(inv_batch)
+        self._check_inputs()
         _lib.check(_lib.lib().mllp_gnn_loss_step(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
                                                  _lib.ptr(self.labels), ib, _lib.ptr(self.workspace()),
                                                  _lib.ptr(logits), _lib.ptr(loss), _lib.ptr(grads),

@@ -786,3 +786,44 @@ def test_fused_path_equals_generic_path(LPBatch, weights):
         bg.forward(flat_gpu)
         close(bf.backward(flat_gpu, dz).cpu().numpy()[grad_mask()], bg.backward(flat_gpu, dz).cpu().numpy()[grad_mask()],
               RTOL_GRAD, "backward from dlogits, fused vs generic")
+
+
+def test_fused_path_follows_in_place_input_changes(LPBatch, subset5, weights):
+    """the fused path caches renumbered copies of x1 / x2 / labels keyed on the pointers.  Inputs changed
+    in place (same pointers) must be picked up -- through torch's version counters in `LPBatch`, through
+    mllp_graph_invalidate_inputs at the C ABI -- and backward refuses a workspace written by the other path."""
+    from mllp_amd import _lib
+    flat, sd, flat_gpu = weights
+    insts = [subset5[n] for n in SUBSET5]
+    bg, bf = LPBatch.from_instances(insts).set_path(1), LPBatch.from_instances(insts).set_path(2)
+    z0 = bf.forward(flat_gpu).clone()
+    for b in (bg, bf):
+        b.x1.mul_(-1.5)                      # same tensors, same addresses, new contents
+        b.x2.add_(0.25)
+        b.labels.copy_(1.0 - b.labels)
+    lg, zg, gg = [t.clone() for t in bg.loss_step(flat_gpu)]
+    lf, zf, gf = [t.clone() for t in bf.loss_step(flat_gpu)]
+    assert not torch.allclose(zf, z0)
+    close(zf.cpu().numpy(), zg.cpu().numpy(), RTOL_ACT, "logits after in-place input change, fused vs generic")
+    close(lf.cpu().numpy(), lg.cpu().numpy(), RTOL_ACT, "loss after in-place input change")
+    close(gf.cpu().numpy()[grad_mask()], gg.cpu().numpy()[grad_mask()], RTOL_GRAD, "grads after in-place input change")
+    # the C ABI itself: without the invalidate call the cached copies are used (documented contract), with it the new ones
+    L = _lib.lib()
+    logits = torch.empty(bf.N, device="cuda")
+    bf.x1.mul_(2.0)
+    args = (bf._h, _lib.ptr(flat_gpu), _lib.ptr(bf.x1), _lib.ptr(bf.x2), _lib.ptr(bf.workspace()), _lib.ptr(logits), _lib.current_stream())
+    _lib.check(L.mllp_gnn_forward(*args))
+    stale = logits.clone()
+    _lib.check(L.mllp_graph_invalidate_inputs(bf._h))
+    _lib.check(L.mllp_gnn_forward(*args))
+    bg.x1.mul_(2.0)
+    close(logits.cpu().numpy(), bg.forward(flat_gpu).cpu().numpy(), RTOL_ACT, "C ABI after mllp_graph_invalidate_inputs")
+    close(stale.cpu().numpy(), zf.cpu().numpy(), RTOL_ACT, "C ABI without invalidate: the cached inputs (contract)")
+    # backward on a workspace that the other path wrote: refused
+    dz = torch.randn(bf.N, device="cuda")
+    bf.forward(flat_gpu)
+    bf.set_path(1)
+    with pytest.raises(_lib.MllpError):
+        bf.backward(flat_gpu, dz)
+    bf.forward(flat_gpu)
+    bf.backward(flat_gpu, dz)                # forward and backward on the same path again: fine

@@ -794,7 +794,7 @@ def test_fused_path_follows_in_place_input_changes(LPBatch, subset5, weights):
     mllp_graph_invalidate_inputs at the C ABI -- and backward refuses a workspace written by the other path."""
     from mllp_amd import _lib
     flat, sd, flat_gpu = weights
-    insts = [subset5[n] for n in SUBSET5]
+    insts = list(subset5)
     bg, bf = LPBatch.from_instances(insts).set_path(1), LPBatch.from_instances(insts).set_path(2)
     z0 = bf.forward(flat_gpu).clone()
     for b in (bg, bf):

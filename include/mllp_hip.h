@@ -168,6 +168,17 @@ int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int variant, int64_t
                             int32_t max_blocks_per_tile /* largest tile_blk[t+1]-tile_blk[t]; at most 255 */,
                             const int32_t* d_tile_blk, const int32_t* d_blk_id, const int32_t* d_ptr2,
                             const int32_t* d_perm, const int32_t* d_ent);
+/* The same copies built by the library on the device from the graph's own CSR (counting passes + one placement pass,
+ * mllp_amd/csrc/tiled_build.hip; not a launch function: allocates and synchronises `stream`).  The arrays are
+ * library-owned: a later build / attach / detach of the same (orientation, variant) and mllp_graph_destroy free them.
+ *   mllp_graph_tiled_info: info[0..4] = row tiles, (tile, block) pairs, most blocks in one tile, 1 if library-owned,
+ *   longest (tile, block) segment in entries (0 for caller-built copies).
+ *   mllp_graph_export_tiled (tests): device-to-device copy of array `which` = 0 tile_blk, 1 blk_id, 2 ptr2, 3 perm,
+ *   4 ent ((nnz + 1) x 2 int32); `count` int32 elements must equal the array's length.                       */
+int mllp_graph_build_tiled(mllp_graph_t* g, int transpose, int variant, void* stream);
+int mllp_graph_tiled_info(const mllp_graph_t* g, int transpose, int variant, int64_t info[5]);
+int mllp_graph_export_tiled(const mllp_graph_t* g, int transpose, int variant, int which, int32_t* d_dst, int64_t count,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One torch_geometric.nn.TransformerConv((cin, cin), 16, edge_dim=1) followed by ReLU, as called at

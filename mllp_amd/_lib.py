@@ -39,6 +39,9 @@ _PROTOTYPES = {
     "mllp_graph_drop_spmm_copy": (c_int, [c_void_p, c_int]),
     "mllp_graph_spmm_copy_info": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "mllp_graph_export_spmm_copy": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64]),
+    "mllp_graph_build_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mllp_graph_tiled_info": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64)]),
+    "mllp_graph_export_tiled": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mllp_spmm_csr_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mllp_spmm_csr_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mllp_angle_num_params": (c_int, [c_int, POINTER(c_int64)]),
@@ -97,6 +100,9 @@ def lib():
             raise MllpError("libmllp_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+MLLP_ERANGE = -4          # include/mllp_hip.h
 
 
 def check(rc):

@@ -317,7 +317,7 @@ extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int varia
     Tiled* tls[5] = {&o.tiled, &o.tiled_attn, &o.tiled_bsrc, &o.tiled_scalar, &o.tiled_bdst};
     Tiled& tl = *tls[variant];
     if (n_tiles == 0) {   // detach
-        tl = Tiled();
+        tiled_free(tl);
         return MLLP_OK;
     }
     REQUIRE(d_tile_blk && d_blk_id && d_ptr2 && d_perm && d_ent, "null array");
@@ -327,9 +327,52 @@ extern "C" int mllp_graph_attach_tiled(mllp_graph_t* g, int transpose, int varia
     REQUIRE(n_tb > 0 && n_tb * (int64_t)R < INT32_MAX, "bad (tile, block) count");
     REQUIRE(max_blocks_per_tile > 0 && max_blocks_per_tile <= tiled_max_blocks_per_tile(),
             "a row tile touches more column blocks than the kernel's table holds");
-    tl.n_tiles = (int)n_tiles; tl.n_tb = (int)n_tb;
+    tiled_free(tl);
+    tl.n_tiles = (int)n_tiles; tl.n_tb = (int)n_tb; tl.max_nbt = max_blocks_per_tile;
     tl.tile_blk = d_tile_blk; tl.blk_id = d_blk_id; tl.ptr2 = d_ptr2; tl.perm = d_perm;
     tl.ent = d_ent;
+    return MLLP_OK;
+}
+
+static Tiled* tiled_slot(mllp_graph_t* g, int transpose, int variant) {
+    Orient& o = transpose ? g->At : g->A;
+    Tiled* tls[5] = {&o.tiled, &o.tiled_attn, &o.tiled_bsrc, &o.tiled_scalar, &o.tiled_bdst};
+    return tls[variant];
+}
+
+extern "C" int mllp_graph_build_tiled(mllp_graph_t* g, int transpose, int variant, void* stream) {
+    REQUIRE(g, "null graph");
+    REQUIRE(variant >= 0 && variant <= 4, "variant must be 0 (SpMM), 1 (attention forward), 2 / 4 (attention backward, source- / destination-major) or 3 (layer-1 sweeps)");
+    Tiled fresh;
+    int rc = build_tiled_device(transpose ? g->At : g->A, g->nnz, variant, fresh, (hipStream_t)stream);
+    if (rc) return rc;
+    Tiled& tl = *tiled_slot(g, transpose, variant);
+    tiled_free(tl);
+    tl = fresh;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_tiled_info(const mllp_graph_t* g, int transpose, int variant, int64_t* info) {
+    REQUIRE(g && info, "null argument");
+    REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
+    const Tiled& tl = *tiled_slot(const_cast<mllp_graph_t*>(g), transpose, variant);
+    info[0] = tl.n_tiles; info[1] = tl.n_tb; info[2] = tl.max_nbt; info[3] = tl.owned ? 1 : 0; info[4] = tl.max_run;
+    return MLLP_OK;
+}
+
+extern "C" int mllp_graph_export_tiled(const mllp_graph_t* g, int transpose, int variant, int which, int32_t* d_dst,
+                                       int64_t count, void* stream) {
+    REQUIRE(g && d_dst, "null argument");
+    REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
+    const Tiled& tl = *tiled_slot(const_cast<mllp_graph_t*>(g), transpose, variant);
+    REQUIRE(tl.n_tiles > 0, "no tiled copy of this variant is attached");
+    int R, CB, CAP;
+    tiled_geometry(variant, &R, &CB, &CAP);
+    const int* src[5] = {tl.tile_blk, tl.blk_id, tl.ptr2, tl.perm, tl.ent};
+    const int64_t n[5] = {tl.n_tiles + 1, tl.n_tb, (int64_t)tl.n_tb * R + 1, (int64_t)tl.n_tb * R, (g->nnz + 1) * 2};
+    REQUIRE(which >= 0 && which < 5, "which must be 0 (tile_blk), 1 (blk_id), 2 (ptr2), 3 (perm) or 4 (ent)");
+    REQUIRE(count == n[which], "count does not match the array's length");
+    MLLP_HIP_TRY(hipMemcpyAsync(d_dst, src[which], (size_t)count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MLLP_OK;
 }
 

@@ -32,8 +32,10 @@ int hip_fail(hipError_t e, const char* what);
 //   group tier: 16 lanes per row (4 rows per wavefront), wave tier: 64 lanes per row,
 //   block tier: one 256-thread workgroup per row.
 // optional LDS-tiled copy of an orientation (tiled_kernels.hip); arrays are borrowed from the caller
+// (mllp_graph_attach_tiled) or owned by the library (mllp_graph_build_tiled: tiled_build.hip)
 struct Tiled {
-    int n_tiles = 0, n_tb = 0;
+    int n_tiles = 0, n_tb = 0, max_nbt = 0, max_run = 0;   // max_run: longest (tile, block) segment (library-built copies)
+    bool owned = false;
     const int* tile_blk = nullptr;   // [n_tiles + 1]
     const int* blk_id = nullptr;     // [n_tb]
     const int* ptr2 = nullptr;       // [n_tb * rows_per_tile + 1] offsets of the length-sorted positions
@@ -185,6 +187,8 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
 int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s);   // stream_build.hip
 void stream_copy_free(StreamCopy& sc);                                                  // stream_api.cpp
+int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hipStream_t s);   // tiled_build.hip
+void tiled_free(Tiled& tl);                                                             // tiled_build.hip (owned arrays only)
 int launch_spmm_stream(const StreamCopy& sc, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
 int launch_spmm_tiled_bf16(const Tiled& tl, int n_dst, int n_src, const void* H_bf16, float* Y, hipStream_t s);

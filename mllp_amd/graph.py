@@ -274,10 +274,12 @@ class LPBatch:
         return (torch.from_numpy(self.export(base)).to(dev), torch.from_numpy(self.export(base + 1)).to(dev),
                 torch.from_numpy(self.export(base + 2)).to(dev))
 
-    def enable_tiled(self, transpose=False, arrays=None, variant=0):
+    def enable_tiled(self, transpose=False, arrays=None, variant=0, builder="device"):
         """Build and attach the LDS-tiled copy of A (transpose=False) or A^T.  Returns a dict with the
         geometry, or None when the matrix does not qualify (index range).
-        Re-blocking is done once with torch ops on the device (plumbing, not the hot path)."""
+        builder="device": the library's HIP builder (mllp_graph_build_tiled, library-owned arrays);
+        builder="torch" (or explicit `arrays`): the torch reference builder `build_tiled_arrays`, whose arrays the
+        library borrows.  `self.tiled_build_s` accumulates the seconds spent building."""
         L = _lib.lib()
         R, CB, CAP = c_int32(), c_int32(), c_int32()
         _lib.check(L.mllp_tiled_geometry(int(variant), ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
@@ -285,11 +287,26 @@ class LPBatch:
         import time
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if arrays is None and builder == "device":
+            rc = L.mllp_graph_build_tiled(self._h, int(transpose), int(variant), _lib.current_stream())
+            torch.cuda.synchronize()
+            self.tiled_build_s = getattr(self, "tiled_build_s", 0.0) + time.perf_counter() - t0
+            if rc == _lib.MLLP_ERANGE:
+                return None
+            _lib.check(rc)
+            if not hasattr(self, "_tiled"):
+                self._tiled = {}
+            self._tiled[(bool(transpose), int(variant))] = None      # library-owned: nothing to keep alive here
+            d = (c_int64 * 5)()
+            _lib.check(L.mllp_graph_tiled_info(self._h, int(transpose), int(variant), d))
+            return dict(rows_per_tile=R, cols_per_block=CB, n_tiles=int(d[0]), n_tb=int(d[1]), max_run=int(d[4]),
+                        staged_bytes=int(d[1]) * CB * 64, gathered_bytes=self.nnz * 64, builder="device")
+        assert builder in ("device", "torch")
         ptr, idx, val = arrays if arrays is not None else self._device_orientation(transpose)
         n_dst = self.N if transpose else self.M
         built = build_tiled_arrays(ptr, idx, val, n_dst, R, CB, variant)
         torch.cuda.synchronize()
-        self.tiled_build_s = getattr(self, "tiled_build_s", 0.0) + time.perf_counter() - t0   # seconds in the torch builder
+        self.tiled_build_s = getattr(self, "tiled_build_s", 0.0) + time.perf_counter() - t0
         if built is None:
             return None
         keep, info = built
@@ -302,7 +319,27 @@ class LPBatch:
         if not hasattr(self, "_tiled"):
             self._tiled = {}
         self._tiled[(bool(transpose), int(variant))] = keep          # the library borrows these arrays
+        info["builder"] = "torch"
         return info
+
+    def export_tiled(self, transpose=False, variant=0):
+        """The attached tiled copy as torch int32 device tensors (tile_blk, blk_id, ptr2, perm, ent [nnz + 1, 2]) (tests)."""
+        L = _lib.lib()
+        R, CB, CAP = c_int32(), c_int32(), c_int32()
+        _lib.check(L.mllp_tiled_geometry(int(variant), ctypes.byref(R), ctypes.byref(CB), ctypes.byref(CAP)))
+        d = (c_int64 * 5)()
+        _lib.check(L.mllp_graph_tiled_info(self._h, int(transpose), int(variant), d))
+        n_tiles, n_tb = int(d[0]), int(d[1])
+        sizes = [n_tiles + 1, n_tb, n_tb * R.value + 1, n_tb * R.value, (self.nnz + 1) * 2]
+        out = []
+        for which, n in enumerate(sizes):
+            t = torch.empty(n, dtype=torch.int32, device=self.x1.device)
+            _lib.check(L.mllp_graph_export_tiled(self._h, int(transpose), int(variant), which, _lib.ptr(t), n,
+                                                 _lib.current_stream()))
+            out.append(t)
+        torch.cuda.synchronize()
+        out[4] = out[4].view(-1, 2)
+        return dict(zip(["tile_blk", "blk_id", "ptr2", "perm", "ent"], out))
 
     # ---- streamed SpMM copy (library-owned; stream_layout.h) -----------------------------------------
     def build_spmm_copy(self, transpose=False, where="device"):

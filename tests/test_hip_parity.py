@@ -827,3 +827,63 @@ def test_fused_path_follows_in_place_input_changes(LPBatch, subset5, weights):
         bf.backward(flat_gpu, dz)
     bf.forward(flat_gpu)
     bf.backward(flat_gpu, dz)                # forward and backward on the same path again: fine
+
+
+def test_device_tiled_builder_layout_and_parity(LPBatch, weights):
+    """mllp_graph_build_tiled (tiled_build.hip) against the layout contract of include/mllp_hip.h and the torch
+    reference builder: tile / block / offset / permutation arrays identical, entries a permutation of the CSR with the
+    right byte offsets (checked like tests/test_hostlogic.py checks the torch builder: ragged last tile, empty rows,
+    an empty instance in the middle), and the training step on device-built copies = on torch-built copies."""
+    from mllp_amd.graph import synthetic_batch
+    from test_hostlogic import _row_entries
+    flat, sd, flat_gpu = weights
+    sb = synthetic_batch(n_inst=3, m=700, n=1300, mean_row_nnz=12.0, seed=91, chunk=1)
+    mult = {0: 64, 1: 64, 2: 160, 3: 4, 4: 64}
+    for tr in (False, True):
+        ptr, idx, val = (t.cpu().numpy() for t in sb._device_orientation(tr))
+        n_dst = sb.N if tr else sb.M
+        want = {(r, int(idx[e])): val[e] for r in range(n_dst) for e in range(ptr[r], ptr[r + 1])}
+        for v in (0, 1, 2, 3, 4):
+            ref = sb.enable_tiled(tr, variant=v, builder="torch")
+            t_arr = {k: a.cpu().numpy().copy() for k, a in sb._tiled[(tr, v)].items()}
+            info = sb.enable_tiled(tr, variant=v)
+            assert info["builder"] == "device" and sb._tiled[(tr, v)] is None
+            for k in ("n_tiles", "n_tb", "max_run", "rows_per_tile", "cols_per_block"):
+                assert info[k] == ref[k], (tr, v, k)
+            d_arr = {k: a.cpu().numpy() for k, a in sb.export_tiled(tr, v).items()}
+            for k in ("tile_blk", "blk_id", "ptr2", "perm"):
+                np.testing.assert_array_equal(d_arr[k], t_arr[k], err_msg=f"{k} tr={tr} variant={v}")
+            R, CB = info["rows_per_tile"], info["cols_per_block"]
+            tile_blk, blk_id, ptr2, perm, ent = (d_arr[k] for k in ("tile_blk", "blk_id", "ptr2", "perm", "ent"))
+            assert ent[-1].tolist() == [0, 0]
+            got = {}
+            for t in range(info["n_tiles"]):
+                for tb in range(tile_blk[t], tile_blk[t + 1]):
+                    runs = _row_entries(ptr2, tb, R, v)
+                    for k in range(R):
+                        row = t * R + int(perm[tb * R + k])
+                        for e in runs[k]:
+                            off = int(ent[e, 0])
+                            assert off % mult[v] == 0 and 0 <= off // mult[v] < CB
+                            key = (row, int(blk_id[tb]) * CB + off // mult[v])
+                            assert key not in got
+                            got[key] = ent[e:e + 1, 1].view(np.float32)[0]
+            assert got.keys() == want.keys(), (tr, v)
+            assert all(got[k] == want[k] for k in want), (tr, v)
+    # whole step: device-built copies vs torch-built copies
+    out = {}
+    for builder in ("torch", "device"):
+        b = synthetic_batch(n_inst=3, m=700, n=1300, mean_row_nnz=12.0, seed=91, chunk=1)
+        for tr in (False, True):
+            for v in (0, 1, 2, 3, 4):
+                assert b.enable_tiled(tr, variant=v, builder=builder) is not None
+        H = torch.randn(b.N, 16, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        out[builder] = [t.clone().cpu().numpy() for t in b.loss_step(flat_gpu)] + [b.spmm(H).cpu().numpy()]
+    close(out["device"][1], out["torch"][1], 5e-6, "logits, device-built vs torch-built tiled copies")
+    close(out["device"][2][grad_mask()], out["torch"][2][grad_mask()], 5e-5, "grads, device-built vs torch-built")
+    close(out["device"][3], out["torch"][3], 2e-6, "A H, device-built vs torch-built")
+    # a rebuild replaces (and frees) the library-owned arrays; detaching twice is harmless
+    assert b.enable_tiled(False, variant=1) is not None
+    b.disable_tiled(False, variant=1)
+    b.disable_tiled(False, variant=1)
+    assert [t.clone().cpu().numpy() for t in b.loss_step(flat_gpu)][1].shape == out["device"][1].shape

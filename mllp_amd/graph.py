@@ -245,6 +245,9 @@ class LPBatch:
         """Batch from device CSR arrays in global ids (int32 ptr/idx, fp32 values).  The transposed
         orientation is built here with one stable device sort (torch -> rocPRIM): plumbing, done once."""
         L = _lib.lib()
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         M, N, nnz = int(sum(inst_m)), int(sum(inst_n)), int(csr_idx.numel())
         rows = torch.repeat_interleave(torch.arange(M, device=csr_idx.device, dtype=torch.int32),
                                        (csr_ptr[1:] - csr_ptr[:-1]).long())
@@ -264,7 +267,9 @@ class LPBatch:
                                               _lib.ptr(csc_ptr), _lib.ptr(csc_idx), _lib.ptr(csc_val),
                                               tier_wave, tier_block, _lib.current_stream(), ctypes.byref(h)))
         torch.cuda.synchronize()
-        return LPBatch(h, M, N, nnz, len(inst_m), inst_m, inst_n, x1, x2, labels, names)
+        b = LPBatch(h, M, N, nnz, len(inst_m), inst_m, inst_n, x1, x2, labels, names)
+        b.graph_build_s = time.perf_counter() - t0     # transposition (one device sort) + row tiers (mllp_graph_create_device)
+        return b
 
     # ---- LDS-tiled copies (throughput regime) -----------------------------------------------------
     def _device_orientation(self, transpose):

@@ -3,10 +3,14 @@
 # passes (separate --pmc runs) and SQ / LDS counters of the streamed SpMM, its in-kernel stamps (timing build).
 mkdir -p gpurun_out/final; export TMPDIR=/tmp
 step() { local name=$1 secs=$2; shift 2; timeout -k 10 "$secs" "$@" > "gpurun_out/final/$name.log" 2>&1; local rc=$?; echo "[$name] rc=$rc"; tail -n 2 "gpurun_out/final/$name.log" | cut -c1-300; if grep -q "Memory access fault" "gpurun_out/final/$name.log"; then exit 9; fi; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi; }
+part=${1:-all}
+if [ $part != b ]; then
 step bench_plain 900 python3 bench.py
 step bench_prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_bench -- python3 bench.py --no-cpu-baseline
 # the raw kernel trace (every torch kernel of the tiled-copy builder included) exceeds what gpurun copies back: keep the summary
 python3 tools/summarize_rocprof.py gpurun_out/final/prof_bench gpurun_out/final/kernel_stats.md > /dev/null; rm -rf gpurun_out/final/prof_bench
+fi
+if [ $part = a ]; then exit 0; fi
 step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_fetch -- python3 tools/profile_stream.py 256 3
 step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pmc_write -- python3 tools/profile_stream.py 256 3
 step pmc_l2 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d gpurun_out/final/pmc_l2 -- python3 tools/profile_stream.py 256 3

@@ -7,10 +7,12 @@
 //   tb_count        per (tile, block, row): entries of the row in the block, CSR position of the first one
 //   tb_sort         per (tile, block): rows by entry count, descending, ties by row (variants 0-3; variant 4 keeps the
 //                   rows in place); offsets of the sorted positions inside the (tile, block) segment
-//   tb_fill         entries.  Variants 0 and 1 (a quad of lanes per row, 16 sorted positions per wavefront): the four
-//                   rows whose quads share a ds_read_b128 lane group are ordered JOINTLY over (column mod 4), one thread
-//                   per such team; variants 2-4: round-robin over (column mod 4) per row, starting at the class of the
-//                   row's quad; variant 4 stores the entries of every 64-row chunk by step.
+//   tb_fill         entries.  Variants 0, 1 (a quad of lanes per row, 16 sorted positions per wavefront) and 4 (a lane
+//                   per row): the four rows that read in the same LDS cycle of a ds_read_b128 are ordered JOINTLY over
+//                   (column mod 4), one thread per such team; variants 2, 3 (and any matrix with a (row, block) run of
+//                   more than 512 entries): round-robin over (column mod 4) per row, starting at the class of the row's
+//                   quad; variant 4 stores the entries of every 64-row chunk by step.
+// Every array comes out bit-identical to graph.py::build_tiled_arrays (tests/test_hip_parity.py).
 // The arrays are library-owned (freed on rebuild / detach / destroy).
 #include <algorithm>
 #include <climits>
@@ -76,7 +78,7 @@ __global__ void tb_count(const int* __restrict__ ptr, const int* __restrict__ id
 
 // perm[tb][k] = row at sorted position k; off[tb][k] = offset of position k inside the segment; seg[tb] = its length
 __global__ void tb_sort(const int* __restrict__ cnt, int R, int keep_order, int* __restrict__ perm, int* __restrict__ off,
-                        int* __restrict__ seg) {
+                        int* __restrict__ seg, int* __restrict__ longest) {
     extern __shared__ int sh[];          // c[R], sorted counts / scan[R]
     int* c = sh;
     int* sc = sh + R;
@@ -107,6 +109,11 @@ __global__ void tb_sort(const int* __restrict__ cnt, int R, int keep_order, int*
     }
     off[tb * R + r] = r ? sc[r - 1] : 0;
     if (r == R - 1) seg[tb] = v;
+    if (r == 0) {                        // longest (row, block) run: the joint entry order is used up to 512 (as graph.py)
+        int m = 0;
+        for (int k = 0; k < R; ++k) m = max(m, c[k]);
+        atomicMax(longest, m);
+    }
 }
 
 __global__ void tb_ptr2(const int* __restrict__ off, const int* __restrict__ seg_start, int R, long long n,
@@ -131,20 +138,34 @@ __global__ void tb_fill(const int* __restrict__ idx, const float* __restrict__ v
     __syncthreads();
     const int c0 = blk_id[tb] * CB;
     if (joint) {
-        const int q = k & 15, b16 = k & ~15;
-        int tm = -1;
-        for (int t = 0; t < 4; ++t)
-            if (TEAMS[t][0] == q) tm = t;
-        if (tm < 0) return;
+        // the four positions of this thread's team (the thread of the team's first position does the work)
+        int pos4[4];
+        if (chunked) {      // a lane per row: lanes of one ds_read_b128 lane group that read with the same rotation (graph.py::LANE_GROUPS)
+            const int lane = k & 63, c64 = k & ~63;
+            if ((lane & 31) >= 8) return;
+            const int r = lane & 3, h = lane & 32;
+            if ((lane & 7) < 4) { pos4[0] = r; pos4[1] = 12 + r; pos4[2] = 20 + r; pos4[3] = 24 + r; }
+            else { pos4[0] = 4 + r; pos4[1] = 8 + r; pos4[2] = 16 + r; pos4[3] = 28 + r; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pos4[i] += c64 + h;
+        } else {
+            const int q = k & 15, b16 = k & ~15;
+            int tm = -1;
+            for (int t = 0; t < 4; ++t)
+                if (TEAMS[t][0] == q) tm = t;
+            if (tm < 0) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pos4[i] = b16 + TEAMS[tm][i];
+        }
         int beg[4], rem[4], nxt[4][4], cl[4][4], base[4];
         int maxlen = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kk = b16 + TEAMS[tm][i];
+            const int kk = pos4[i];
             const int rr = perm[tb * R + kk];
             beg[i] = start[tb * R + rr];
             rem[i] = sh[kk];
-            base[i] = ptr2[tb * R + kk];
+            base[i] = chunked ? ptr2[tb * R + (kk & ~63)] : ptr2[tb * R + kk];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { nxt[i][c] = 0; cl[i][c] = 0; }
             for (int e = 0; e < rem[i]; ++e) {
@@ -180,7 +201,16 @@ __global__ void tb_fill(const int* __restrict__ idx, const float* __restrict__ v
                         if (c == pick) { nxt[i][c] = e + 1; cl[i][c] -= 1; }
                     rem[i] -= 1;
                     used |= 1u << pick;
-                    ent[base[i] + p] = make_int2((idx[beg[i] + e] - c0) * item_bytes, __float_as_int(val[beg[i] + e]));
+                    int dest = base[i] + p;
+                    if (chunked) {       // step p of lane l: behind steps < p of every lane of the chunk and step p of the lanes < l
+                        const int c64 = pos4[i] & ~63;
+                        dest = base[i];
+                        for (int l = 0; l < 64; ++l) {
+                            const int ll = sh[c64 + l];
+                            dest += min(ll, p) + ((c64 + l < pos4[i] && ll > p) ? 1 : 0);
+                        }
+                    }
+                    ent[dest] = make_int2((idx[beg[i] + e] - c0) * item_bytes, __float_as_int(val[beg[i] + e]));
                 }
             }
         }
@@ -244,7 +274,7 @@ int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hi
     const int item_bytes = variant == 2 ? 160 : variant == 3 ? 4 : 64;
     const int n_tiles = (int)(((int64_t)o.n_dst + R - 1) / R);
     if (nnz == 0 || n_tiles == 0) return fail(MLLP_EINVAL, "tiled copy: the matrix has no nonzeros");
-    DevBuf<int> lo, hi, cnt, start, off, seg, seg_start;
+    DevBuf<int> lo, hi, cnt, start, off, seg, seg_start, longest;
     if (lo.alloc(n_tiles) || hi.alloc(n_tiles)) return fail(MLLP_ENOMEM, "tiled copy: hipMalloc failed");
     const int T = ((R + 63) / 64) * 64;
     hipLaunchKernelGGL(tb_tile_range, dim3(n_tiles), dim3(T), 0, s, o.ptr, o.idx, o.n_dst, R, CB, lo.p, hi.p);
@@ -280,7 +310,7 @@ int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hi
     if (hipMalloc((void**)&d_tile_blk, ((size_t)n_tiles + 1) * 4) != hipSuccess || hipMalloc((void**)&d_blk, std::max<size_t>(n_tb, 1) * 4) != hipSuccess ||
         hipMalloc((void**)&d_ptr2, (n_slots + 1) * 4) != hipSuccess || hipMalloc((void**)&d_perm, std::max<size_t>(n_slots, 1) * 4) != hipSuccess ||
         hipMalloc((void**)&d_ent, ((size_t)nnz + 1) * 8) != hipSuccess || cnt.alloc(n_slots) || start.alloc(n_slots) || off.alloc(n_slots) ||
-        seg.alloc((size_t)n_tb) || seg_start.alloc((size_t)n_tb)) {
+        seg.alloc((size_t)n_tb) || seg_start.alloc((size_t)n_tb) || longest.alloc(1)) {
         cleanup();
         return fail(MLLP_ENOMEM, "tiled copy: hipMalloc failed");
     }
@@ -291,13 +321,15 @@ int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hi
         (e = hipMemcpyAsync(lo.p, h_lo.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemsetAsync(cnt.p, 0, std::max<size_t>(n_slots, 1) * 4, s)) != hipSuccess ||
         (e = hipMemsetAsync(start.p, 0, std::max<size_t>(n_slots, 1) * 4, s)) != hipSuccess ||
-        (e = hipMemsetAsync(d_ent + (size_t)nnz * 2, 0, 8, s)) != hipSuccess)
+        (e = hipMemsetAsync(d_ent + (size_t)nnz * 2, 0, 8, s)) != hipSuccess || (e = hipMemsetAsync(longest.p, 0, 4, s)) != hipSuccess)
         return bail(e, "tiled copy: copy / memset");
     hipLaunchKernelGGL(tb_count, dim3(n_tiles), dim3(T), 0, s, o.ptr, o.idx, o.n_dst, R, CB, lo.p, d_tile_blk, cnt.p, start.p);
     hipLaunchKernelGGL(tb_sort, dim3((unsigned)n_tb), dim3(R), (size_t)2 * R * 4, s, cnt.p, R, variant == 4 ? 1 : 0, d_perm,
-                       off.p, seg.p);
+                       off.p, seg.p, longest.p);
     std::vector<int> h_seg((size_t)n_tb), h_seg_start((size_t)n_tb);
+    int h_longest = 0;
     if ((e = hipMemcpyAsync(h_seg.data(), seg.p, (size_t)n_tb * 4, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(&h_longest, longest.p, 4, hipMemcpyDeviceToHost, s)) != hipSuccess ||
         (e = hipStreamSynchronize(s)) != hipSuccess)
         return bail(e, "tiled copy: segment lengths");
     int64_t run = 0;
@@ -316,7 +348,7 @@ int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hi
     const long long n_p = (long long)n_slots;
     hipLaunchKernelGGL(tb_ptr2, dim3((unsigned)((n_p + 256) / 256)), dim3(256), 0, s, off.p, seg_start.p, R, n_p, (int)nnz, d_ptr2);
     hipLaunchKernelGGL(tb_fill, dim3((unsigned)n_tb), dim3(R), (size_t)R * 4, s, o.idx, o.val, d_blk, cnt.p, start.p, d_perm,
-                       d_ptr2, R, CB, item_bytes, (variant == 0 || variant == 1) ? 1 : 0, variant == 4 ? 1 : 0,
+                       d_ptr2, R, CB, item_bytes, ((variant == 0 || variant == 1 || variant == 4) && h_longest <= 512) ? 1 : 0, variant == 4 ? 1 : 0,
                        reinterpret_cast<int2*>(d_ent));
     if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "tiled copy: kernels");
     tl.tile_blk = d_tile_blk; tl.blk_id = d_blk; tl.ptr2 = d_ptr2; tl.perm = d_perm; tl.ent = d_ent;

@@ -831,7 +831,7 @@ def test_fused_path_follows_in_place_input_changes(LPBatch, subset5, weights):
 
 def test_device_tiled_builder_layout_and_parity(LPBatch, weights):
     """mllp_graph_build_tiled (tiled_build.hip) against the layout contract of include/mllp_hip.h and the torch
-    reference builder: tile / block / offset / permutation arrays identical, entries a permutation of the CSR with the
+    reference builder: all five arrays bit-identical, entries a permutation of the CSR with the
     right byte offsets (checked like tests/test_hostlogic.py checks the torch builder: ragged last tile, empty rows,
     an empty instance in the middle), and the training step on device-built copies = on torch-built copies."""
     from mllp_amd.graph import synthetic_batch
@@ -851,7 +851,7 @@ def test_device_tiled_builder_layout_and_parity(LPBatch, weights):
             for k in ("n_tiles", "n_tb", "max_run", "rows_per_tile", "cols_per_block"):
                 assert info[k] == ref[k], (tr, v, k)
             d_arr = {k: a.cpu().numpy() for k, a in sb.export_tiled(tr, v).items()}
-            for k in ("tile_blk", "blk_id", "ptr2", "perm"):
+            for k in ("tile_blk", "blk_id", "ptr2", "perm", "ent"):          # bit for bit, entry order included
                 np.testing.assert_array_equal(d_arr[k], t_arr[k], err_msg=f"{k} tr={tr} variant={v}")
             R, CB = info["rows_per_tile"], info["cols_per_block"]
             tile_blk, blk_id, ptr2, perm, ent = (d_arr[k] for k in ("tile_blk", "blk_id", "ptr2", "perm", "ent"))

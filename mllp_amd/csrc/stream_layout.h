@@ -10,27 +10,27 @@
 //   * LDS then holds TWO images of H (filled by LDS-DMA, no registers) + the tile's accumulators: image b + 1
 //     lands while image b is walked; one barrier per block.
 //
-// Geometry: row tiles of at most S_R = 1024 destination rows x column blocks of S_CB = 625 source nodes.  The first
+// Geometry: row tiles of at most S_RR = 960 destination rows (S_R = 1024 row slots) x column blocks of S_CB = 750 source nodes.  The first
 // version (512 x 1000) measured bound by the CU's vector-memory fill path, not by LDS (profiles/r03_stream_*): every
 // tile stages every block of its instance, 6400 / S_R bytes of H per nonzero at 1 % density whatever S_CB is, most of
 // it L2 hits but 40 % of them misses (the hot H of the 2-3 instances an XCD works on does not fit its 4 MB L2 next to
-// the entry stream).  1024 rows halve that traffic; 64 KB of accumulators + 2 x (40 000 B + one all-zero row) of
-// images = 145 664 B of LDS.  Tiles never cross an instance boundary (tile_row): a tile that straddles two instances
+// the entry stream).  1024 row slots halve that traffic; 64 KB of accumulators + 2 x (48 000 B + one all-zero row) of
+// images = 161 664 B of LDS.  Tiles never cross an instance boundary (tile_row): a tile that straddles two instances
 // would stage the blocks of both for half the rows each.
 //
 // Work split inside a (tile, block): the rows are ordered by their number of entries in the block (descending, ties
-// by row id) and cut into S_NB = 32 BUNDLES of 16 S_RQ = 32 positions.  Wavefront w (of S_NW = 16) walks S_P = 2
-// passes, pass j over bundle 16 j + (j odd ? 15 - w : w) (long rows with short rows: equal step counts for all
-// wavefronts).  In a pass, quad q of the wavefront owns S_RQ = 2 rows, slot r = position 32 b + 16 r + q; a STEP is one
+// by row id) and cut into S_NB = 16 BUNDLES of S_BR = 64 positions.  Wavefront w (of S_NW = 8) walks S_P = 2
+// passes, pass j over bundle 8 j + (j odd ? 7 - w : w) (long rows with short rows: similar step counts for all
+// wavefronts).  In a pass, quad q of the wavefront owns S_RQ = 4 rows, slot r = position 64 b + 16 r + q; a STEP is one
 // entry of each of the quad's rows for each of the 16 quads; the pass takes n = (entries of the bundle's longest
 // row) steps, shorter rows are padded with entries {zero row, 0.0f} that read the all-zero row behind the image
-// (4 % of the slots on the synthetic batch).
+// (10 % of the slots on the synthetic batch).
 // Tiles hold at most S_RR = 960 rows: the missing rows sort last and form the empty bundle 15, so wavefront 0, whose
 // bundle 0 holds the rows of the long tail, has no second pass.  With 1024 rows its two passes took 1.38 x the steps of
 // the average wavefront and everybody waited for it at the barrier of every block; with 960 it is 1.16 x.
-// (Why 16 wavefronts of little work each: a wavefront issues about one instruction per 4-5 cycles whatever the
-// instruction is; with 8 walking wavefronts, 4 rows per quad, the walk of a block took ~5 000 cycles of which the LDS
-// reads and the FMAs together accounted for 900 -- profiles/r03_stream_experiments.txt.)
+// (Why 8 wavefronts of 4 rows per quad rather than 16 of 2: a wavefront issues about one instruction per 4-5 cycles
+// whatever the instruction is, and the address / broadcast / guard instructions of a step are per quad-row group, not per
+// row -- profiles/r03_stream_experiments.txt.)
 //
 // Arrays:
 //   tile_row [n_tiles + 1]   first destination row of each tile (rows of tile t: tile_row[t] .. tile_row[t + 1] - 1)

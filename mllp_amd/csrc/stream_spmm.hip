@@ -2,27 +2,23 @@
 // (layout, geometry and the reasons: stream_layout.h).  The reference's equivalent is the gather / scale / scatter-add
 // of PyG's message passing over `edge_index`, `edge_attr` (linear_program_methods.py:241-247).
 //
-// Workgroup = one row tile (at most 1024 rows of one instance) = 16 wavefronts on one CU, all with the same role:
-//   entries    each wavefront holds, in registers, its own entries of the current (tile, block): one register set per
-//              pass (S_K0 / S_K1 groups, 12 bytes per lane and group); a group is reloaded with the NEXT block's
-//              entries (coalesced non-temporal loads, one per site) as soon as its last step is done, so one set
-//              serves both blocks and the entries never touch LDS.
-//   walk       two passes per block, S_RQ rows per quad: per step and quad one entry of each row, shared inside the
+// Workgroup = one row tile (at most 960 rows of one instance) on one CU: 8 walking wavefronts + 4 staging wavefronts.
+//   entries    each walking wavefront holds, in registers, its own entries of the current (tile, block): one register
+//              set per pass (S_K0 / S_K1 groups, 12 bytes per lane and group); a group is reloaded with the NEXT block's
+//              entries (coalesced non-temporal loads, one per site) as soon as its last step is done, so the entries
+//              never touch LDS.  The pass-1 set is double-buffered (its reload is hidden behind pass 0 of the next block).
+//   walk       two passes per block, S_RQ = 4 rows per quad: per step and quad one entry of each row, shared inside the
 //              quad by DPP, one ds_read_b128 of the source row per entry, two packed FMAs per lane.  The steps are
-//              static code, software-pipelined by hand (the reads of step s + SK_D are issued before the FMAs of step
-//              s); the rows' accumulators are read from LDS at the start of a pass and written back at its end.
-//   staging    the NEXT block's 750 x 64 B of H by LDS-DMA (global_load_lds_dwordx4: no
-//              registers, no ds_write) into the image that is not being read, one piece per site.
+//              static code, software-pipelined by hand, one inline-asm statement per step (`sk_site`): the reads of step
+//              s are issued before the FMAs of step s - 1.  The rows' accumulators live in fixed registers during a pass:
+//              read from LDS at its start, written back at its end.
+//   staging    the NEXT block's 750 x 64 B of H by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) into
+//              the image that is not being read, by the 4 staging wavefronts, paced with s_sleep.
 //   barrier    one per block: behind it image b + 1 and everybody's entries of block b + 1 have landed (vmcnt(0) on
 //              every wavefront, MI355X_MICROARCH.md "Two waves per SIMD" item 7) and the reads of image b are done.
-//   LDS        image 0 | image 1 (48 000 B + one all-zero row each) | accumulators of the tile (64 KB) | dummy words.
-// Three things are done by hand because hipcc's s_waitcnt insertion cannot see through them
-// (profiles/r03_stream_experiments.txt):
-//   * the LDS-DMA is issued from inline asm: behind a visible global_load_lds every LDS read waits for vmcnt(0) (the
-//     destination may alias);
-//   * the LDS reads of the walk and their counted waits are inline asm: across the conditionally executed sites the
-//     compiler merges the LDS counter state into lgkmcnt(0) in front of every group of reads and of FMAs;
-//   * a site without a real step issues dummy LDS writes, so that the wait count is one constant.
+//   LDS        image 0 | image 1 (48 000 B + one all-zero row each) | accumulators of the tile (64 KB).
+// What is done by hand because hipcc's register allocation and s_waitcnt insertion cannot see through it
+// (profiles/r03_stream_experiments.txt): see the comment at `sk_site`.
 // Deterministic: a row of a (tile, block) belongs to one quad, blocks are walked in order, no atomics.
 #include <cstdlib>
 #include <type_traits>
@@ -49,7 +45,8 @@ constexpr int SK_PPW = (SK_PIECES + SK_NSTG - 1) / SK_NSTG;   // pieces per stag
 #endif
 constexpr int SK_D = MLLP_SK_D; // pipeline depth in steps: D + 1 sets of read results
 constexpr int SK_NQ = (SK_D + 1) * S_RQ;        // register quads that the asm owns: D + 1 sets of S_RQ rows
-constexpr int SK_VGPRS = 168 - 4 * SK_NQ;       // what is left for the compiler
+constexpr int SK_VGPRS = 114;                   // what is left for the compiler: the asm owns v128-v167
+static_assert(SK_D == 1 && S_RQ == 4 && S_GS == 2, "the hand-written sites are for one step in flight, four rows per quad");
 static_assert(SK_NQ <= 16, "SK_QUADS names 16 quads");
 static_assert(SK_LDS + 256 <= 163840 && SK_THREADS <= 1024, "one CU");
 
@@ -88,83 +85,122 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
-// The walk's LDS reads land in FIXED registers that the compiler never sees: the kernel is compiled for
-// 168 - 4 SK_NQ VGPRs (amdgpu_num_vgpr) and the quads above that are named in the asm text, written by ds_read_b128 and
-// read by v_pk_fma_f32 / v_pk_add_f32, all inline asm, ordered by `volatile` and by the counted waits between them.
-// (An asm read's destination is written when the data returns, long after the statement.  With compiler-allocated
-// destinations hipcc copied such values at control-flow joins before the wait -- stale data, and the late write then
-// landed in a register it had reused: wrong results and a memory fault, profiles/r03_stream_experiments.txt.)
-// Quad I = v[164 - 4 I : 167 - 4 I].
-#define SK_QUADS(F)                                                                                                   \
-    F(0, "164", "165", "166", "167") F(1, "160", "161", "162", "163") F(2, "156", "157", "158", "159")                 \
-    F(3, "152", "153", "154", "155") F(4, "148", "149", "150", "151") F(5, "144", "145", "146", "147")                 \
-    F(6, "140", "141", "142", "143") F(7, "136", "137", "138", "139") F(8, "132", "133", "134", "135")                 \
-    F(9, "128", "129", "130", "131") F(10, "124", "125", "126", "127") F(11, "120", "121", "122", "123")               \
-    F(12, "116", "117", "118", "119") F(13, "112", "113", "114", "115") F(14, "108", "109", "110", "111")              \
-    F(15, "104", "105", "106", "107")
-template <int I>
-__device__ __forceinline__ void xq_read(unsigned addr) {
-#define SK_F(N, A, B, C, D)                                                                                           \
-    if constexpr (I == N)                                                                                             \
-        asm volatile("ds_read_b128 v[" A ":" D "], %0" : : "v"(addr) : "memory", "v" A, "v" B, "v" C, "v" D);
-    SK_QUADS(SK_F)
-#undef SK_F
+// The walk is hand-written: one asm statement per SITE (the reads of step s, then the FMAs of step s - 1 behind a counted
+// wait), on FIXED registers that the compiler never sees -- the kernel is compiled for SK_VGPRS = 114 VGPRs
+// (amdgpu_num_vgpr) and everything above is named in the asm text:
+//   v[164:167] v[160:163] v[156:159] v[152:155]   source rows of an EVEN step (rows 0-3 of the quad)
+//   v[148:151] v[144:147] v[140:143] v[136:139]   source rows of an ODD step
+//   v135  this lane's offset of the step; v134  LDS address; v[132:133], v[114:115]  a row's value as pk_fma operand
+//   v[116:131]  the accumulators of the quad's four rows (this lane's four channels of each)
+// Why by hand (profiles/r03_stream_experiments.txt): an asm read's destination is written when the data returns, long
+// after the statement -- with compiler-allocated destinations hipcc copied such values at control-flow joins before
+// the wait (stale data; the late write then landed in a register it had reused: a memory fault); with compiler-issued
+// reads it merges the LDS counter state of conditionally executed sites into lgkmcnt(0); and between DPP instructions
+// that it allocates to one register it inserts s_nop's for the `old` operand that bound_ctrl never reads.  A wavefront
+// issues about one instruction per 4-5 cycles whatever it is, so the instruction count per step bounds the walk: 22 per
+// site here (+ 2 scalar for the guard and the hook's conditional load), 43 in the compiler-scheduled version.
+// tools/check_asm_reads.py verifies on the generated assembly, at every build, that no compiler-generated instruction
+// names a reserved register and that no VALU result is read by a DPP instruction of the asm within two instructions.
+#ifdef MLLP_SK_WAIT8      // (experiment: timing of a deeper pipeline; the results are wrong)
+#define SK_WAITN "s_waitcnt lgkmcnt(8)\n\t"
+#else
+#define SK_WAITN "s_waitcnt lgkmcnt(4)\n\t"
+#endif
+#define SK_DPP(K) " quad_perm:[" #K "," #K "," #K "," #K "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define SK_READS(Q0, Q1, Q2, Q3)                                                   \
+    "v_add_u32_dpp v134, v135, %[pb]" SK_DPP(0) "ds_read_b128 v[" Q0 "], v134\n\t"  \
+    "v_add_u32_dpp v134, v135, %[pb]" SK_DPP(1) "ds_read_b128 v[" Q1 "], v134\n\t"  \
+    "v_add_u32_dpp v134, v135, %[pb]" SK_DPP(2) "ds_read_b128 v[" Q2 "], v134\n\t"  \
+    "v_add_u32_dpp v134, v135, %[pb]" SK_DPP(3) "ds_read_b128 v[" Q3 "], v134\n\t"
+#define SK_VAL(K, P) "v_mov_b32_dpp v" P ", %[val]" SK_DPP(K)
+#define SK_FMA2(P, A, B, X0, X1)                                                   \
+    "v_pk_fma_f32 v[" A "], v[" P "], v[" X0 "], v[" A "] op_sel_hi:[0,1,1]\n\t"       \
+    "v_pk_fma_f32 v[" B "], v[" P "], v[" X1 "], v[" B "] op_sel_hi:[0,1,1]\n\t"
+// (the values of rows 0 and 1 are broadcast in front of the reads -- SK_VAL01: they fill the two wait states between the
+// write of v135 and its first DPP read)
+#define SK_VAL01 SK_VAL(0, "132") SK_VAL(1, "114")
+#define SK_FMAS(A0, A1, B0, B1, C0, C1, D0, D1)                                                                  \
+    SK_FMA2("132:133", "116:117", "118:119", A0, A1) SK_FMA2("114:115", "120:121", "122:123", B0, B1)            \
+    SK_VAL(2, "132") SK_VAL(3, "114")                                                                            \
+    SK_FMA2("132:133", "124:125", "126:127", C0, C1) SK_FMA2("114:115", "128:129", "130:131", D0, D1)
+#define SK_READS_EVEN SK_READS("164:167", "160:163", "156:159", "152:155")
+#define SK_READS_ODD SK_READS("148:151", "144:147", "140:143", "136:139")
+#define SK_FMAS_EVEN SK_FMAS("164:165", "166:167", "160:161", "162:163", "156:157", "158:159", "152:153", "154:155")
+#define SK_FMAS_ODD SK_FMAS("148:149", "150:151", "144:145", "146:147", "140:141", "142:143", "136:137", "138:139")
+#define SK_CLOBBER                                                                                                    \
+    "memory", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", \
+        "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",      \
+        "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154",      \
+        "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+
+// site of step S (parity PAR = S & 1): reads of step S, FMAs of step S - 1.  `o`: the lane's offset word of the group of
+// step S, `val`: its value of step S - 1.  MODE 0 = both, 1 = reads only (first step of a pass), 2 = FMAs only (behind the
+// last step).  ABL (timing build): 4 = no LDS reads, 8 = no FMAs.
+template <int PAR, int MODE, int ABL>
+__device__ __forceinline__ void sk_site(int o, int val, unsigned pb) {
+    constexpr bool RD = MODE != 2 && !(ABL & 4), FM = MODE != 1 && !(ABL & 8);
+    if constexpr (RD && FM) {
+        if constexpr (PAR == 0)
+            asm volatile("v_and_b32 v135, 0xffff, %[o]\n\t" SK_VAL01 SK_READS_EVEN SK_WAITN SK_FMAS_ODD
+                         : : [o] "v"(o), [val] "v"(val), [pb] "v"(pb) : SK_CLOBBER);
+        else
+            asm volatile("v_lshrrev_b32 v135, 16, %[o]\n\t" SK_VAL01 SK_READS_ODD SK_WAITN SK_FMAS_EVEN
+                         : : [o] "v"(o), [val] "v"(val), [pb] "v"(pb) : SK_CLOBBER);
+    } else if constexpr (RD) {
+        if constexpr (PAR == 0)
+            asm volatile("v_and_b32 v135, 0xffff, %[o]\n\ts_nop 1\n\t" SK_READS_EVEN : : [o] "v"(o), [pb] "v"(pb) : SK_CLOBBER);
+        else
+            asm volatile("v_lshrrev_b32 v135, 16, %[o]\n\ts_nop 1\n\t" SK_READS_ODD : : [o] "v"(o), [pb] "v"(pb) : SK_CLOBBER);
+    } else if constexpr (FM) {
+        if constexpr (PAR == 0)     // (the step whose FMAs these are is odd)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\t" SK_VAL01 SK_FMAS_ODD : : [val] "v"(val) : SK_CLOBBER);
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\t" SK_VAL01 SK_FMAS_EVEN : : [val] "v"(val) : SK_CLOBBER);
+    }
 }
-// lo += v * quad.xy, hi += v * quad.zw (v = low half of vv)
-template <int I>
-__device__ __forceinline__ void xq_fma(f32x2s vv, f32x2s& lo, f32x2s& hi) {
-#define SK_F(N, A, B, C, D)                                                                                           \
-    if constexpr (I == N)                                                                                             \
-        asm volatile("v_pk_fma_f32 %0, %2, v[" A ":" B "], %0 op_sel_hi:[0,1,1]\n\t"                                  \
-                     "v_pk_fma_f32 %1, %2, v[" C ":" D "], %1 op_sel_hi:[0,1,1]"                                      \
-                     : "+v"(lo), "+v"(hi) : "v"(vv) : "v" A, "v" B, "v" C, "v" D);
-    SK_QUADS(SK_F)
-#undef SK_F
+// the accumulators of the quad's four rows (v[116:131]): read from / written back to the tile's accumulators in LDS
+__device__ __forceinline__ void sk_acc_load(unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile("ds_read_b128 v[116:119], %0\n\tds_read_b128 v[120:123], %1\n\tds_read_b128 v[124:127], %2\n\t"
+                 "ds_read_b128 v[128:131], %3" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : SK_CLOBBER);
 }
-template <int I>
-__device__ __forceinline__ void xq_add(f32x2s& lo, f32x2s& hi) {
-#define SK_F(N, A, B, C, D)                                                                                           \
-    if constexpr (I == N)                                                                                             \
-        asm volatile("v_pk_add_f32 %0, %0, v[" A ":" B "]\n\tv_pk_add_f32 %1, %1, v[" C ":" D "]"                      \
-                     : "+v"(lo), "+v"(hi) : : "v" A, "v" B, "v" C, "v" D);
-    SK_QUADS(SK_F)
-#undef SK_F
-}
-// one 4-byte LDS write (a lane's own word of a dummy region) that only keeps the count of outstanding LDS operations
-// uniform.  A write, not a read: nothing would keep the compiler from reusing a dummy read's destination register
-// before the data lands in it.
-__device__ __forceinline__ void lds_pad(unsigned addr) {
-    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(0.0f) : "memory");
+__device__ __forceinline__ void sk_acc_store(unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b128 %0, v[116:119]\n\tds_write_b128 %1, v[120:123]\n\t"
+                 "ds_write_b128 %2, v[124:127]\n\tds_write_b128 %3, v[128:131]" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : SK_CLOBBER);
 }
 template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
 }
 
-// Static sites of a pass (compile-time recursion: the register sets must be indexed by constants): site S issues the
-// reads of step S, does the FMAs of step S - D behind a wait for "at most S_RQ D LDS operations outstanding", and calls
-// hook(S) -- unconditionally, so that what the hook issues (the next block's entries, one load per site: a burst at
-// the top of the block fills the CU's vector-memory queue and every wavefront stands in the issue of its loads; the
-// LDS-DMA pieces) sits at fixed program points and the compiler's vmcnt counts stay exact.  Steps [ra, rb) of the
-// S_GS K steps held in registers.  The D sites behind the last step issue dummy LDS writes instead of reads, so the
-// wait count is the same constant at every site: the instruction count per site bounds the walk (a wavefront issues
-// one instruction per 4-5 cycles).
-template <int S, int K, class FI, class FP, class FF, class FH>
-__device__ __forceinline__ void stream_sites(int ra, int rb, FI&& issue_s, FP&& pad_s, FF&& fma_s, FH&& hook) {
-    if constexpr (S < S_GS * K + SK_D) {
-        if (S >= ra && S < rb + SK_D) {                                  // wave-uniform
-            if constexpr (S < S_GS * K) {
-                if (S < rb) issue_s(std::integral_constant<int, S>());
-                else pad_s();
-            } else {
-                pad_s();        // (steps behind the register set are walked by the slow path, not pipelined)
+// Static sites of a pass (compile-time recursion: the entry registers must be indexed by constants).  `cur` holds S_GS K
+// steps from the group of the pass's first step on; the pass walks steps [ra, rb) of them, ra = 0 or 1.  hook(S) runs at
+// every site, behind the walk's end too: what it issues (the next block's entries, one conditional load per site -- a
+// burst at the top of the block fills the CU's vector-memory queue and every wavefront stands in the issue of its
+// loads) sits at fixed program points.  Steps behind the register set are walked by the slow path of `pass`.
+template <int S, int K, int ABL, class Cur, class FH>
+__device__ __forceinline__ void stream_sites(int ra, int rb, const Cur& cur, unsigned pb, FH&& hook) {
+    constexpr int N = S_GS * K;
+    if constexpr (S <= N) {
+        constexpr int g = (S < N ? S : N - 1) / S_GS, gp = (S > 0 ? S - 1 : 0) / S_GS;
+        const int o = cur[g].o;                                                   // offsets of step S (S < N)
+        const int v = ((S - 1) & 1) ? cur[gp].v1 : cur[gp].v0;                    // value of step S - 1 (S > 0)
+        if constexpr (S == 0) {
+            if (ra == 0 && 0 < rb) sk_site<0, 1, ABL>(o, 0, pb);
+        } else if constexpr (S == 1) {
+            if (1 < rb) {
+                if (ra == 0) sk_site<1, 0, ABL>(o, v, pb);
+                else sk_site<1, 1, ABL>(o, 0, pb);
+            } else if (ra == 0 && rb == 1) {
+                sk_site<1, 2, ABL>(0, v, pb);
             }
-            if constexpr (S >= SK_D) {
-                if (S - SK_D >= ra) fma_s(std::integral_constant<int, S - SK_D>());
-            }
+        } else if constexpr (S < N) {
+            if (__builtin_expect(S < rb, 1)) sk_site<S & 1, 0, ABL>(o, v, pb);
+            if (__builtin_expect(S == rb, 0)) sk_site<S & 1, 2, ABL>(0, v, pb);
+        } else {
+            if (N <= rb) sk_site<S & 1, 2, ABL>(0, v, pb);                    // (the slow path continues from here)
         }
         hook(std::integral_constant<int, S>());
-        stream_sites<S + 1, K>(ra, rb, issue_s, pad_s, fma_s, hook);
+        stream_sites<S + 1, K, ABL>(ra, rb, cur, pb, hook);
     }
 }
 
@@ -283,82 +319,52 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS
         constexpr int K = decltype(kk)::value;
         if (ABL & 1) a = b;
         if ((ABL & 256) && wave != 0) a = b;      // timing only: one wavefront walks alone
-        int ri[S_RQ];
-#pragma unroll
-        for (int r = 0; r < S_RQ; ++r) ri[r] = ((((r & 2) ? r23 : r01) >> (16 * (r & 1))) & 0xffff) * 4 + part;
-        // accumulators of the rows: ordinary (compiler-managed) reads in front of the first site -- the asm statements
-        // are memory barriers for the compiler, so they are issued here -- added behind the last step
-        float4 y[S_RQ];
-#pragma unroll
-        for (int r = 0; r < S_RQ; ++r) y[r] = Ya[ri[r]];
-        f32x2s acc[2 * S_RQ];
-#pragma unroll
-        for (int r = 0; r < 2 * S_RQ; ++r) acc[r] = f32x2s{0.f, 0.f};
-        const int ra = a % S_GS, rb = b - (a - ra);
-        const unsigned pad_addr = (unsigned)(SK_LDS + lane * 4);
-        stream_sites<0, K>(
-            ra, rb,
-            [&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                constexpr int l0 = ((s % S_GS) >> 1) * S_RQ;        // lane (of the quad) that holds slot 0 of step s
-                constexpr int q0 = (s % (SK_D + 1)) * S_RQ;         // first register quad of the step's read set
-                // this lane's offset of step s (meaningful in the lanes that hold step s: part / S_RQ == (s % S_GS) / 2)
-                const int o = (s & 1) ? (int)((unsigned)cur[s / S_GS].o >> 16) : (cur[s / S_GS].o & 0xffff);
-                if (ABL & 4) return;
-                xq_read<q0>(pb + qbcast<l0>(o));
-                xq_read<q0 + 1>(pb + qbcast<l0 + 1>(o));
-                if constexpr (S_RQ == 4) {
-                    xq_read<q0 + 2>(pb + qbcast<(l0 + 2) & 3>(o));
-                    xq_read<q0 + 3>(pb + qbcast<(l0 + 3) & 3>(o));
-                }
-            },
-            [&]() {
-                if (ABL & 4) return;
-#pragma unroll
-                for (int r = 0; r < S_RQ; ++r) lds_pad(pad_addr);
-            },
-            [&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                constexpr int l0 = ((f % S_GS) >> 1) * S_RQ;
-                constexpr int q0 = (f % (SK_D + 1)) * S_RQ;
-                if (!(ABL & 4)) lds_wait<S_RQ * SK_D>();
-                const int v = (f & 1) ? cur[f / S_GS].v1 : cur[f / S_GS].v0;
-                if (ABL & 8) {
-                    acc[0].x += __int_as_float(v);
-                    return;
-                }
-                xq_fma<q0>(f32x2s{__int_as_float(qbcast<l0>(v)), 0.f}, acc[0], acc[1]);
-                xq_fma<q0 + 1>(f32x2s{__int_as_float(qbcast<l0 + 1>(v)), 0.f}, acc[2], acc[3]);
-                if constexpr (S_RQ == 4) {
-                    xq_fma<q0 + 2>(f32x2s{__int_as_float(qbcast<(l0 + 2) & 3>(v)), 0.f}, acc[4], acc[5]);
-                    xq_fma<q0 + 3>(f32x2s{__int_as_float(qbcast<(l0 + 3) & 3>(v)), 0.f}, acc[6], acc[7]);
-                }
-            },
-            [&](auto hc_) {
-                constexpr int site = decltype(hc_)::value;
-                constexpr int h = site - (S_GS - 1) - SK_D;             // site of the last FMA of group h / S_GS
-                if constexpr (h >= 0 && h % S_GS == 0 && h / S_GS < K) {
-                    // (only the groups the next block's pass will use: the CU's vector-memory path, ~30 B/clk, is what
-                    // bounds the kernel, and loading the whole set every block tripled the entry bytes through it)
-                    if (h / S_GS < gn && !(ABL & 64)) cur[h / S_GS] = ld3(np + 64 * (h / S_GS));
-                }
-                extra(hc_);
-            });
-        lds_wait<0>();      // nothing is in flight into the asm's registers from here on
-        for (int st = S_GS * K; st < rb; ++st) {
-            const Ent3 e = ld3(t.ent + (size_t)(a / S_GS + st / S_GS) * 64 + lane);
-            const int o = (st & 1) ? (int)((unsigned)e.o >> 16) : (e.o & 0xffff), v = (st & 1) ? e.v1 : e.v0;
-            const int l0 = ((st % S_GS) >> 1) * S_RQ;
-#pragma unroll
-            for (int r = 0; r < S_RQ; ++r) {
-                const int src = (lane & ~3) | ((l0 + r) & 3);
-                const f32x4s xs = *reinterpret_cast<const f32x4s*>(smem + (pb + __shfl(o, src, 64)));
-                pk4(__int_as_float(__shfl(v, src, 64)), xs, acc[2 * r], acc[2 * r + 1]);
-            }
-        }
+        unsigned ya[S_RQ];      // LDS byte addresses of the rows' accumulators (this lane's 16-byte piece)
 #pragma unroll
         for (int r = 0; r < S_RQ; ++r)
-            Ya[ri[r]] = make_float4(acc[2 * r].x + y[r].x, acc[2 * r].y + y[r].y, acc[2 * r + 1].x + y[r].z, acc[2 * r + 1].y + y[r].w);
+            ya[r] = (unsigned)(SK_YA + (((((r & 2) ? r23 : r01) >> (16 * (r & 1))) & 0xffff) * 4 + part) * 16);
+        const int ra = a % S_GS, rb = b - (a - ra);
+        const bool any = rb > ra;                                                   // wave-uniform
+        if (any) sk_acc_load(ya[0], ya[1], ya[2], ya[3]);
+        stream_sites<0, K, ABL>(ra, rb, cur, pb, [&](auto hc_) {
+            constexpr int site = decltype(hc_)::value;
+            constexpr int h = site - (S_GS - 1) - SK_D;             // site of the last FMA of group h / S_GS
+            if constexpr (h >= 0 && h % S_GS == 0 && h / S_GS < K) {
+                // (only the groups the next block's pass will use: the CU's vector-memory path, ~30 B/clk, is what
+                // bounds the kernel, and loading the whole set every block tripled the entry bytes through it)
+                if (__builtin_expect(h / S_GS < gn, 1) && !(ABL & 64)) cur[h / S_GS] = ld3(np + 64 * (h / S_GS));
+            }
+            extra(hc_);
+        });
+        if (any) sk_acc_store(ya[0], ya[1], ya[2], ya[3]);      // (waits for lgkmcnt(0) first)
+        if (rb > S_GS * K) {
+            // slow path: the steps behind the register set (a row with dozens of entries inside one block), fetched
+            // group by group and accumulated in ordinary registers, added to the rows' accumulators in LDS at the end
+            // (nothing of the asm's is live here: under register pressure the compiler may use v116-v167 between the two
+            // markers, and only there -- tools/check_asm_reads.py)
+            asm volatile("; SK_SLOW_BEGIN" : : : "memory");
+            f32x2s acc[2 * S_RQ];
+#pragma unroll
+            for (int r = 0; r < 2 * S_RQ; ++r) acc[r] = f32x2s{0.f, 0.f};
+            for (int st = S_GS * K; st < rb; ++st) {
+                const Ent3 e = ld3(t.ent + (size_t)(a / S_GS + st / S_GS) * 64 + lane);
+                const int o = (st & 1) ? (int)((unsigned)e.o >> 16) : (e.o & 0xffff), v = (st & 1) ? e.v1 : e.v0;
+#pragma unroll
+                for (int r = 0; r < S_RQ; ++r) {
+                    const int src = (lane & ~3) | r;
+                    const f32x4s xs = *reinterpret_cast<const f32x4s*>(smem + (pb + __shfl(o, src, 64)));
+                    pk4(__int_as_float(__shfl(v, src, 64)), xs, acc[2 * r], acc[2 * r + 1]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < S_RQ; ++r) {
+                float4* yp = reinterpret_cast<float4*>(smem + ya[r]);
+                const float4 y = *yp;
+                *yp = make_float4(y.x + acc[2 * r].x, y.y + acc[2 * r].y, y.z + acc[2 * r + 1].x, y.w + acc[2 * r + 1].y);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): no compiler-tracked LDS operation stays pending
+            asm volatile("; SK_SLOW_END" : : : "memory");
+        }
     };
     SK_TICK(0)
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): image 0 and the first entries have landed
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_num_vgpr(SK_VGPRS
         pass(ea, npa, gna, std::integral_constant<int, S_K0>(), rc.x, rc.y, S_, S_ + n0_, pb_, [&](auto sc) {
             constexpr int s = decltype(sc)::value;
             if constexpr (s % 2 == 0 && s / 2 < S_K1) {     // the next block's pass-1 entries, one group per even site
-                if (s / 2 < gnb && !(ABL & 64)) ebn[s / 2] = ld3(npb + 64 * (s / 2));
+                if (__builtin_expect(s / 2 < gnb, 1) && !(ABL & 64)) ebn[s / 2] = ld3(npb + 64 * (s / 2));
             }
             if constexpr (!SK_STAGERS && s % 3 == 1 && s / 3 < SK_PPW) {    // the LDS-DMA pieces of the next image
                 if (more) stage_piece(nblk, nimg, s / 3);
@@ -444,7 +450,7 @@ int launch_spmm_stream(const StreamCopy& sc, int n_dst, int n_src, const float* 
     if (const char* e = getenv("MLLP_STREAM_ABLATION")) abl = atoi(e);
 #define SK_LAUNCH(A) \
     if (abl == A) hipLaunchKernelGGL(spmm_stream_kernel<A>, dim3(sc.n_tiles), dim3(SK_THREADS), 0, s, t, H, Y);
-    SK_LAUNCH(1) SK_LAUNCH(2) SK_LAUNCH(3) SK_LAUNCH(4) SK_LAUNCH(8) SK_LAUNCH(12) SK_LAUNCH(16) SK_LAUNCH(18) SK_LAUNCH(28) SK_LAUNCH(80) SK_LAUNCH(272) SK_LAUNCH(284)
+    SK_LAUNCH(1) SK_LAUNCH(2) SK_LAUNCH(3) SK_LAUNCH(4) SK_LAUNCH(8) SK_LAUNCH(12) SK_LAUNCH(16) SK_LAUNCH(18) SK_LAUNCH(20) SK_LAUNCH(24) SK_LAUNCH(28) SK_LAUNCH(80) SK_LAUNCH(272) SK_LAUNCH(284)
 #undef SK_LAUNCH
 #endif
     if (abl == 0) hipLaunchKernelGGL(spmm_stream_kernel<0>, dim3(sc.n_tiles), dim3(SK_THREADS), 0, s, t, H, Y);

@@ -1,38 +1,72 @@
 #!/usr/bin/env python3
-"""Guard for stream_spmm.hip: the registers that the hand-written LDS reads land in (quads named in the asm text,
-v[first:167]) must not appear in any compiler-generated instruction while such a read may be in flight, i.e. between an
-asm `ds_read_b128` and the asm `s_waitcnt lgkmcnt(0)` that ends the pass (linear scan of the assembly: the sites of a
-pass are laid out in program order) -- the data lands there asynchronously and only the asm's counted waits order its
-use.  Elsewhere the asm statements' clobber lists keep the compiler from holding live values in them.  usage: python3 tools/check_asm_reads.py <file.s> <first reserved vgpr>  (exit 1 on a
-violation)"""
+"""Guard for stream_spmm.hip, run on the generated assembly at every build (mllp_amd/csrc/Makefile).
+The walk of spmm_stream_kernel is inline asm on FIXED registers v[first:167] (LDS read destinations that are written
+asynchronously, temporaries of the DPP broadcasts).  Checked here:
+  1. no compiler-generated instruction names a register >= first (the kernel is compiled with amdgpu_num_vgpr(first),
+     which is a soft cap: this makes it a hard one) -- except between the asm markers `; SK_SLOW_BEGIN` and
+     `; SK_SLOW_END` (the slow path of a pass, entered behind the write-back of the accumulators, when nothing of the asm's
+     is live; the scan is linear, so a slow-path block that the compiler lays out elsewhere fails the build);
+  2. DPP hazard (2 wait states between a VALU write of a VGPR and a DPP read of it): for every *_dpp instruction inside
+     an asm statement whose DPP source (src0) is a compiler-allocated register, neither of the two instructions in front of
+     it (inside the asm or before it) is a VALU instruction writing that register.
+usage: python3 tools/check_asm_reads.py <file.s> <first reserved vgpr>  (exit 1 on a violation)"""
 import re, sys
 
 path, first = sys.argv[1], int(sys.argv[2])
-bad, in_asm, n_asm_reads, in_flight = 0, False, 0, False
 reg_re = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs(tok):
+    out = set()
+    for m in reg_re.finditer(tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+bad, in_asm, n_asm_reads, n_dpp, slow = 0, False, 0, 0, False
+prev = []          # the last two instructions: (text, is_valu, registers written)
 for no, ln in enumerate(open(path).read().splitlines(), 1):
-    s = ln.strip()
+    s = ln.split(";")[0].strip() if not ln.strip().startswith(";;#") else ln.strip()
     if s.startswith(";;#ASMSTART"):
         in_asm = True
         continue
     if s.startswith(";;#ASMEND"):
         in_asm = False
         continue
-    if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+    if in_asm and "SK_SLOW_BEGIN" in ln:
+        slow = True
+    if in_asm and "SK_SLOW_END" in ln:
+        slow = False
+    if not s or s.startswith(".") or s.endswith(":"):
         continue
+    ops = s.split(None, 1)
+    mnem, rest = ops[0], (ops[1] if len(ops) > 1 else "")
+    fields = [f.strip() for f in rest.split(",")]
+    is_valu = mnem.startswith("v_")
+    written = regs(fields[0]) if is_valu and fields else set()
     if in_asm:
-        if s.startswith("ds_read_b128"):
+        if mnem == "ds_read_b128":
             n_asm_reads += 1
-            in_flight = True
-        if s.startswith("s_waitcnt lgkmcnt(0)"):
-            in_flight = False
-        continue
-    if not in_flight:
-        continue
-    for m in reg_re.finditer(s):
-        hi = int(m.group(2)) if m.group(1) else int(m.group(3))
-        if hi >= first:
-            print(f"{path}:{no}: compiler-generated `{s}` names a reserved register")
-            bad += 1
-print(f"{path}: {n_asm_reads} asm reads, {bad} violation(s)")
+        if mnem.endswith("_dpp"):
+            n_dpp += 1
+            src0 = regs(fields[1].split()[0]) if len(fields) > 1 else set()
+            for ptxt, pvalu, pw in prev[-2:]:
+                if pvalu and (pw & src0):
+                    print(f"{path}:{no}: `{s}` reads by DPP what `{ptxt}` wrote less than two instructions earlier")
+                    bad += 1
+    elif not slow:
+        for r in regs(s):
+            if r >= first:
+                print(f"{path}:{no}: compiler-generated `{s}` names the reserved register v{r}")
+                bad += 1
+                break
+    if mnem == "s_nop":
+        n = int(rest.strip() or 0) + 1
+        prev = (prev + [("s_nop", False, set())] * n)[-2:]
+    else:
+        prev = (prev + [(s, is_valu, written)])[-2:]
+print(f"{path}: {n_asm_reads} asm reads, {n_dpp} asm DPP instructions, {bad} violation(s)")
 sys.exit(1 if bad else 0)

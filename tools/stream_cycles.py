@@ -40,7 +40,7 @@ for tr in ((False, True) if both else (False,)):
     for abl, name in ABL:
         os.environ["MLLP_STREAM_ABLATION"] = str(abl)
         print(f"   {name:40s} {timed(lambda: b.spmm(H, transpose=tr, out=Y)):.3f} ms")
-    for stamp in (16, 18, 28):
+    for stamp in (16, 18, 20, 24, 28):
         os.environ["MLLP_STREAM_ABLATION"] = str(stamp)
         print(f"  -- stamps, ablation bits {stamp - 16} (2 = no staging, 4 = no LDS reads, 8 = no FMAs, 64 = no entry reloads, 256 = only wavefront 0 walks: its time = 16 x the walk figure)")
         for _ in range(2):

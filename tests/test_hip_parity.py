@@ -941,3 +941,88 @@ def test_cfg2_trajectory_100_adam_steps_vs_oracle(LPBatch, subset5, weights):
     dw = np.abs(tr.params.cpu().numpy().astype(np.float64) - ot.params.numpy())[keep]
     print(f"cfg2 trajectory: max |dw| {dw.max():.2e}, mean {dw.mean():.2e}")
     assert dw.max() < 1e-4
+
+
+_HIP_DP_WORKER = """
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from mllp_amd.data import load_packed, SUBSET5
+from mllp_amd.graph import LPBatch
+from mllp_amd.trainer import LPTrainer, allreduce_sum_, shard_instances
+dist.init_process_group("gloo")            # one GPU on the test box: both ranks use cuda:0, gloo carries the all-reduce
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+inst = load_packed(SUBSET5)
+golden = np.load(os.path.join({root!r}, "tests", "golden", "subset5.npz"), allow_pickle=False)
+params = torch.tensor(golden["weights_flat"], dtype=torch.float32).cuda()       # the `weights` fixture of the tests
+out = {{}}
+for mode, use_graph in (("eager", False), ("graph", True)):
+    shard = [inst[i] for i in shard_instances([i.nnz for i in inst], world)[rank]]
+    batch = LPBatch.from_instances(shard)
+    tr = LPTrainer(params, lr=1e-3, use_hip_graph=use_graph, global_instances=len(inst))
+    losses = []
+    for _ in range(4):
+        loss, _ = tr.step(batch)
+        total = loss.clone()
+        allreduce_sum_(total)
+        losses.append(float(total[0]))
+    # a global batch of ONE instance: rank 1 owns nothing and takes the empty step (experiment.py's per-instance loop)
+    one = LPBatch.from_instances([inst[0]])
+    tr.global_instances = 1
+    for _ in range(2):
+        if rank == 0:
+            tr.step(one)
+        else:
+            tr.step_empty()
+    assert tr.uses_graph(batch) == use_graph
+    out[mode + "_losses"] = np.array(losses)
+    out[mode + "_params"] = tr.params.cpu().numpy()
+    out[mode + "_adam_steps"] = np.array([float(tr.opt.state[0])])
+np.savez({out!r} + str(rank) + ".npz", **out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_hip_trainer_two_ranks_equals_one_process(tmp_path, subset5, weights):
+    """The HIP LPTrainer with TWO data-parallel ranks: LPT shards of the 5-instance batch, the gradient
+    all-reduce between `mllp_gnn_loss_step` and `mllp_adam_step`, the two-graph capture path, and `step_empty` of a
+    rank that owns no instance -- against the same steps in one process.  The test box has one GPU, so both ranks run
+    their kernels on cuda:0 and gloo carries the 18.9 KB all-reduce (RCCL needs one device per rank; the kernels, the
+    sharding and the step logic are the ones the multi-GPU run uses)."""
+    import subprocess
+    import sys
+    from mllp_amd.trainer import LPTrainer
+    flat, sd, flat_gpu = weights
+    script = tmp_path / "w.py"
+    out = str(tmp_path / "dp_rank")
+    script.write_text(_HIP_DP_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = [np.load(out + f"{k}.npz") for k in (0, 1)]
+    # one process, same schedule
+    full = LPBatch_from(subset5)
+    one = LPBatch_from([subset5[0]])
+    tr = LPTrainer(flat_gpu, lr=1e-3, use_hip_graph=False, global_instances=len(subset5))
+    losses = [float(tr.step(full)[0][0]) for _ in range(4)]
+    tr.global_instances = 1
+    for _ in range(2):
+        tr.step(one)
+    want = tr.params.cpu().numpy()
+    keep = grad_mask()
+    for mode in ("eager", "graph"):
+        for k in (0, 1):
+            np.testing.assert_allclose(got[k][mode + "_losses"], losses, rtol=1e-5, err_msg=f"{mode} rank {k}")
+            assert got[k][mode + "_adam_steps"][0] == 6.0
+        # replicated weights: identical on both ranks (same all-reduced gradient, same Adam), equal to one process up to
+        # the summation order of the two shard gradients
+        np.testing.assert_array_equal(got[0][mode + "_params"], got[1][mode + "_params"])
+        np.testing.assert_allclose(got[0][mode + "_params"][keep], want[keep], rtol=1e-4, atol=2e-5, err_msg=mode)
+
+
+def LPBatch_from(instances):
+    from mllp_amd.graph import LPBatch as _B
+    return _B.from_instances(list(instances))

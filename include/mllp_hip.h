@@ -237,6 +237,19 @@ int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, const float
 int mllp_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
                    float* d_state, float eps, float grad_scale, int64_t n, void* stream);
 
+/* One whole training step of a single rank: mllp_gnn_loss_step followed by mllp_adam_step (grad_scale 1) on the
+ * MLLP_NUM_PARAMS parameters -- the body of the reference's loop, linear_program_experiment.py:139-144 -- with the same
+ * results bit for bit.  On the latency-regime path (batches below 32 M nonzeros) the end of the step runs as ONE launch:
+ * reduction of the statistics, the gradients of the five convs, Adam, and the folded weights of the NEXT step, which
+ * are left in the workspace.  flags bit 0: "the folded weights in d_ws are current" -- set it when the previous call on
+ * this d_ws was mllp_gnn_train_step with these d_params and nothing else has written d_params since; the forward then
+ * skips its weight-folding launch.  With several ranks the gradient all-reduce sits between the two halves, so a
+ * data-parallel caller keeps calling mllp_gnn_loss_step and mllp_adam_step.                                      */
+int mllp_gnn_train_step(const mllp_graph_t* g, float* d_params, const float* d_x1, const float* d_x2,
+                        const float* d_labels, float inv_batch, void* d_ws, float* d_logits, float* d_loss,
+                        float* d_grads, float* d_exp_avg, float* d_exp_avg_sq, float* d_state, float eps, int flags,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Prediction + metrics (linear_program_experiment.py:146-151): per instance k, mark the m_k largest
  * logits, correct_k = |pred & basis|, f1_k = 2TP / (2TP + FP + FN).

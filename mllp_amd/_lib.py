@@ -60,6 +60,8 @@ _PROTOTYPES = {
     "mllp_gnn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mllp_gnn_loss_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mllp_gnn_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "mllp_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64,
                                c_void_p]),
     "mllp_metrics_scratch_bytes": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -467,6 +467,28 @@ extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, 
     return model_backward_body(g, d_params, d_x1, d_x2, w, d_grads, s);
 }
 
+extern "C" int mllp_gnn_train_step(const mllp_graph_t* g, float* d_params, const float* d_x1, const float* d_x2,
+                                   const float* d_labels, float inv_batch, void* d_ws, float* d_logits, float* d_loss,
+                                   float* d_grads, float* d_exp_avg, float* d_exp_avg_sq, float* d_state, float eps,
+                                   int flags, void* stream) {
+    REQUIRE(g && d_params && d_x1 && d_x2 && d_labels && d_ws && d_logits && d_loss && d_grads, "null argument");
+    REQUIRE(d_exp_avg && d_exp_avg_sq && d_state, "null optimizer state");
+    REQUIRE((flags & ~1) == 0, "flags: bit 0 = the folded weights in the workspace are current");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (use_fused(g)) {
+        ModelWs w = model_ws(g, (float*)d_ws);
+        const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, d_labels, inv_batch, d_logits);
+        if ((rc = fused_forward(const_cast<mllp_graph*>(g), m, 2, s, (flags & 1) != 0))) return rc;
+        const FusedAdam a = {d_params, d_exp_avg, d_exp_avg_sq, d_state, eps, (int)MLLP_NUM_PARAMS};
+        return fused_backward(g, m, true, d_grads, d_loss, s, &a);
+    }
+    // throughput regime: the same two calls a caller would make (the tail is 0.1 % of such a step)
+    if ((rc = mllp_gnn_loss_step(g, d_params, d_x1, d_x2, d_labels, inv_batch, d_ws, d_logits, d_loss, d_grads, stream)))
+        return rc;
+    return launch_adam(d_params, d_grads, d_exp_avg, d_exp_avg_sq, d_state, eps, 1.0f, MLLP_NUM_PARAMS, s);
+}
+
 extern "C" int mllp_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
                               float* d_state, float eps, float grad_scale, int64_t n, void* stream) {
     REQUIRE(d_params && d_grads && d_exp_avg && d_exp_avg_sq && d_state, "null argument");

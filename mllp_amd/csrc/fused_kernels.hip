@@ -32,6 +32,7 @@
 #include "device_utils.h"
 #include "host_graph.h"
 #include "internal.h"
+#include "node_bodies.h"
 
 namespace mllp {
 
@@ -1593,7 +1594,7 @@ struct ReduceArgs {
     float* loss_out;          // nullable
 };
 
-__global__ __launch_bounds__(RT) void fused_reduce_kernel(ReduceArgs A, int n_conv) {
+__device__ __forceinline__ void fused_reduce_body(const ReduceArgs& A, int n_conv) {
     __shared__ float sh[32][32];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == n_conv * STAT_TILES) {     // fc partials: 32 slices x 18 columns
@@ -1638,6 +1639,68 @@ __global__ __launch_bounds__(RT) void fused_reduce_kernel(ReduceArgs A, int n_co
     sh4[slice * 256 + col] = v;
     __syncthreads();
     if (tid < 256) A.out[c][tile * 256 + tid] = (sh4[tid] + sh4[256 + tid]) + (sh4[512 + tid] + sh4[768 + tid]);
+}
+__global__ __launch_bounds__(RT) void fused_reduce_kernel(ReduceArgs A, int n_conv) { fused_reduce_body(A, n_conv); }
+
+// ====================================================================================================
+// The tail of a single-rank training step in ONE launch (mllp_gnn_train_step): reduce -> gradients of the five convs ->
+// Adam -> folded weights of the next step.  All 36 workgroups sum the partials, ONE grid barrier (the grid is far smaller
+// than the GPU, so every workgroup is resident; the spin is bounded all the same), then a workgroup per conv does
+// gradients -> Adam -> folded weights of its conv with workgroup barriers only.  Separately the four launches take
+// 27 us of a 342 us step; a first version with a grid barrier between each of the four phases took the same 28 us
+// (a barrier = an L2 write-back + invalidate on 8 XCDs), this one ~22 us.
+// ====================================================================================================
+struct TailArgs {
+    ReduceArgs R;
+    ConvParams p[MODEL_CONVS];      // (point into `params`: read by phase B before Adam, by phase D after it)
+    int cin[MODEL_CONVS];
+    float* grads[MODEL_CONVS];
+    float* zero;                    // gradient of the never-used gconv3_s2w
+    int n_zero;
+    float* params; const float* grads_all; float* m; float* v; float* state;
+    float eps;
+    int n_params;
+    float* D[MODEL_CONVS];          // folded weights (the batch's workspace)
+    unsigned long long* sync;       // [0] arrivals (cumulative over launches), [1] launches so far
+};
+__device__ __forceinline__ void tail_barrier(unsigned long long* cnt, unsigned long long target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;      // (bounded: a workgroup that is never scheduled must not hang the others)
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22))
+            __builtin_amdgcn_s_sleep(8);
+        __threadfence();
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(RT) void fused_tail_kernel(TailArgs A, int n_conv) {
+    const unsigned long long G = gridDim.x, epoch = A.sync[1];
+    const int b = blockIdx.x;
+    // (every workgroup reads the optimizer's scalars before the barrier; one of them writes the step count behind it)
+    const float step = A.state[0] + 1.0f, lr = A.state[1], b1 = A.state[2], b2 = A.state[3];
+    fused_reduce_body(A.R, n_conv);                                         // all workgroups: the partials
+    tail_barrier(A.sync, (epoch + 1) * G);
+    // From here on a workgroup works on ITS conv alone: gradients -> Adam on the conv's parameter range -> folded
+    // weights; no conv needs another one's result (the never-used gconv3_s2w has zero gradients and zero moments: Adam
+    // leaves it where it is, exactly as the separate launch does).
+    if (b < n_conv) {
+        finalize_conv_body(A.cin[b], A.p[b], A.R.out[b], 1, A.grads[b]);
+        __syncthreads();
+        const int off = (int)(A.grads[b] - A.grads_all), n = 4 * FEAT * A.cin[b] + 5 * FEAT;
+        adam_slice(A.params + off, A.grads_all + off, A.m + off, A.v + off, step, lr, b1, b2, A.eps, 1.0f, n);
+        __syncthreads();
+        if (threadIdx.x < BLOCK) param_prep_body(A.p[b], A.cin[b], A.D[b]);
+    } else if (b == n_conv) {
+        for (int k = threadIdx.x; k < A.n_zero; k += RT) A.zero[k] = 0.0f;
+        const int off = (int)(A.R.head_out - A.grads_all);                  // fc: 16 weights + bias, behind the convs
+        adam_slice(A.params + off, A.grads_all + off, A.m + off, A.v + off, step, lr, b1, b2, A.eps, 1.0f, A.n_params - off);
+        if (threadIdx.x == 0) {
+            A.state[0] = step;
+            A.sync[1] = epoch + 1;
+        }
+    }
 }
 
 // ====================================================================================================
@@ -1745,6 +1808,10 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((rc = dev_alloc(g, (size_t)g->N, &g->x1_p))) return rc;
     if ((rc = dev_alloc(g, (size_t)g->M, &g->x2_p))) return rc;
     if ((rc = dev_alloc(g, (size_t)g->N, &g->labels_p))) return rc;
+    if (!g->tail_sync) {
+        if ((rc = dev_alloc(g, (size_t)2, &g->tail_sync))) return rc;
+        MLLP_HIP_TRY(hipMemset(g->tail_sync, 0, 16));
+    }
     if (g->M > 0) {
         hipLaunchKernelGGL(fused_fill_kernel, dim3((unsigned)((g->M + 3) / 4)), dim3(256), 0, 0, (int)g->M, g->perm_c, g->A.ptr,
                            g->A.idx, g->A.val, g->inv_v, A.sptr, reinterpret_cast<int2*>(A.sent));
@@ -1820,11 +1887,11 @@ static FwdJob1 fwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, 
     return J;
 }
 
-int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s) {
+int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s, bool skip_prep) {
     const int G = fused_grid(g);
     int rc;
     if ((rc = fused_bind(g, m.x1, m.x2, head_mode == 2 ? m.labels : nullptr, s))) return rc;
-    {   // folded weights of all five convs
+    if (!skip_prep) {   // folded weights of all five convs (skipped when the previous step's tail left them in this workspace)
         const float* cps[MODEL_CONVS] = {m.cp[0], m.cp[1], m.cp[2], m.cp[3], m.cp[4]};
         const int cins[MODEL_CONVS] = {1, 1, 16, 16, 16};
         float* ders[MODEL_CONVS] = {m.c[0].derived, m.c[1].derived, m.c[2].derived, m.c[3].derived, m.c[4].derived};
@@ -1909,7 +1976,8 @@ static BwdJob1 bwd_job1(const FusedOrient& o, const float* cp, const ConvWs& w, 
 //   K4  C2C src  -> d1v_b = (h1v > 0) (dX + d1v)
 //   K5  C1C dst (g = d1c_b) and C1V dst (g = d1v_b) in one launch
 //   K6  reduce the statistics partials (+ fc partials), K7 finalize (node_kernels.hip)
-int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s) {
+int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s,
+                   const FusedAdam* adam) {
     const int G = fused_grid(g);
     int rc;
     const FusedOrient& A = g->FA;      // rows = constraints
@@ -1954,22 +2022,40 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         hipLaunchKernelGGL(fused_bwd1_kernel, dim3(G), dim3(FT), 0, s, L);
         if ((rc = check_launch("fused_bwd1"))) return rc;
     }
+    ReduceArgs R = {};
+    for (int i = 0; i < MODEL_CONVS; ++i) { R.stats[i] = m.c[i].stats; R.out[i] = m.c[i].red; }
+    R.nblk = G;
+    R.head_part = m.have_head_part ? m.head_part : nullptr;
+    R.head_out = grads + 4704;
+    R.loss_out = loss;
+    const int cins[MODEL_CONVS] = {1, 1, 16, 16, 16};
+    float* grs[MODEL_CONVS] = {grads + 0, grads + 144, grads + 288, grads + 1392, grads + 2496};
+    if (adam) {     // K6 + K7 + Adam + the next step's folded weights in one launch (single-rank step)
+        TailArgs T = {};
+        T.R = R;
+        for (int i = 0; i < MODEL_CONVS; ++i) {
+            T.p[i] = conv_params_at(m.cp[i], cins[i]);
+            T.cin[i] = cins[i];
+            T.grads[i] = grs[i];
+            T.D[i] = m.c[i].derived;
+        }
+        T.zero = grads + 3600;
+        T.n_zero = 1104;
+        T.params = adam->params; T.grads_all = grads; T.m = adam->m; T.v = adam->v; T.state = adam->state;
+        T.eps = adam->eps;
+        T.n_params = adam->n;
+        T.sync = g->tail_sync;
+        hipLaunchKernelGGL(fused_tail_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(RT), 0, s, T, MODEL_CONVS);
+        return check_launch("fused_tail");
+    }
     {   // K6
-        ReduceArgs R = {};
-        for (int i = 0; i < MODEL_CONVS; ++i) { R.stats[i] = m.c[i].stats; R.out[i] = m.c[i].red; }
-        R.nblk = G;
-        R.head_part = m.have_head_part ? m.head_part : nullptr;
-        R.head_out = grads + 4704;
-        R.loss_out = loss;
         hipLaunchKernelGGL(fused_reduce_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(RT), 0, s, R, MODEL_CONVS);
         if ((rc = check_launch("fused_reduce"))) return rc;
     }
     {   // K7: the 16x16 algebra of every conv, and the zero gradient of the never-used gconv3_s2w
         const float* cps[MODEL_CONVS] = {m.cp[0], m.cp[1], m.cp[2], m.cp[3], m.cp[4]};
-        const int cins[MODEL_CONVS] = {1, 1, 16, 16, 16};
         const float* sts[MODEL_CONVS] = {m.c[0].red, m.c[1].red, m.c[2].red, m.c[3].red, m.c[4].red};
         const int nbs[MODEL_CONVS] = {1, 1, 1, 1, 1};
-        float* grs[MODEL_CONVS] = {grads + 0, grads + 144, grads + 288, grads + 1392, grads + 2496};
         if ((rc = launch_finalize_batch(MODEL_CONVS, cps, cins, sts, nbs, grs, grads + 3600, 1104, s))) return rc;
     }
     return MLLP_OK;

@@ -119,6 +119,7 @@ struct mllp_graph {
     int* inv_v = nullptr;        // [N] original -> renumbered
     int* inv_c = nullptr;        // [M]
     float* inv_n_p = nullptr;    // [N] 1 / n_k in renumbered order
+    unsigned long long* tail_sync = nullptr;   // [2] grid-barrier state of fused_tail_kernel {arrivals, launches}
     float* x1_p = nullptr;       // [N] bound inputs in renumbered order
     float* x2_p = nullptr;       // [M]
     float* labels_p = nullptr;   // [N]
@@ -251,11 +252,18 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
 int fused_grid(const mllp_graph* g);
 int fused_bind(mllp_graph* g, const float* x1, const float* x2, const float* labels, hipStream_t s);
 // head_mode 1: logits (h3v kept), 2: logits + BCE + masked dL/dh3v in d3v + fc partials
-int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s);
+int fused_forward(mllp_graph* g, const FusedModel& m, int head_mode, hipStream_t s, bool skip_prep = false);
 // d3v = dlogits (original variable order) x fc weight in renumbered order, fc gradient partials
 int fused_head_backward(const mllp_graph* g, const FusedModel& m, const float* dlogits, hipStream_t s);
 // premasked: d3v and the fc partials come from fused_forward(head_mode 2); else d3v = dL/dh3v (unmasked) and the
 // caller has produced the fc gradient itself
-int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s);
+// adam != nullptr: the single-rank tail (reduce + gradients + Adam + the next step's folded weights in one launch)
+struct FusedAdam {
+    float *params, *m, *v, *state;
+    float eps;
+    int n;
+};
+int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, float* grads, float* loss, hipStream_t s,
+                   const FusedAdam* adam = nullptr);
 
 }  // namespace mllp

@@ -487,6 +487,7 @@ class LPBatch:
         if logits is None:
             logits = torch.empty(self.N, device=params.device, dtype=torch.float32)
         self._check_inputs()
+        self._folded = None
         _lib.check(_lib.lib().mllp_gnn_forward(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
                                                _lib.ptr(self.workspace()), _lib.ptr(logits), _lib.current_stream()))
         return logits
@@ -508,10 +509,34 @@ class LPBatch:
         grads = torch.empty(_lib.NUM_PARAMS, device=dev, dtype=torch.float32) if grads is None else grads
         ib = (1.0 / self.n_inst) if inv_batch is None else float(inv_batch)
         self._check_inputs()
+        self._folded = None          # (this call folds the weights of ITS params into the workspace)
         _lib.check(_lib.lib().mllp_gnn_loss_step(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
                                                  _lib.ptr(self.labels), ib, _lib.ptr(self.workspace()),
                                                  _lib.ptr(logits), _lib.ptr(loss), _lib.ptr(grads),
                                                  _lib.current_stream()))
+        return loss, logits, grads
+
+    def train_step(self, params, exp_avg, exp_avg_sq, state, eps=1e-8, inv_batch=None, logits=None, loss=None, grads=None,
+                   param_gen=None):
+        """loss_step + Adam in one library call (single rank; reference experiment.py:139-144).  On the latency-regime
+        path the end of the step is one launch that also folds the weights for the next step into this batch's
+        workspace; the next train_step on this batch skips its folding launch when `params` is provably unchanged since:
+        same tensor, same torch version counter, and the caller's `param_gen` (a counter the caller bumps whenever the
+        library writes `params` outside this method; None = never skip) is the one this call left behind."""
+        dev = params.device
+        logits = torch.empty(self.N, device=dev, dtype=torch.float32) if logits is None else logits
+        loss = torch.empty(1, device=dev, dtype=torch.float32) if loss is None else loss
+        grads = torch.empty(_lib.NUM_PARAMS, device=dev, dtype=torch.float32) if grads is None else grads
+        ib = (1.0 / self.n_inst) if inv_batch is None else float(inv_batch)
+        self._check_inputs()
+        key = (params.data_ptr(), params._version, param_gen)
+        weights_folded = param_gen is not None and getattr(self, "_folded", None) == key
+        _lib.check(_lib.lib().mllp_gnn_train_step(self._h, _lib.ptr(params), _lib.ptr(self.x1), _lib.ptr(self.x2),
+                                                  _lib.ptr(self.labels), ib, _lib.ptr(self.workspace()), _lib.ptr(logits),
+                                                  _lib.ptr(loss), _lib.ptr(grads), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                                  _lib.ptr(state), float(eps), int(bool(weights_folded)),
+                                                  _lib.current_stream()))
+        self._folded = None if param_gen is None else (params.data_ptr(), params._version, param_gen + 1)
         return loss, logits, grads
 
     def topm_metrics(self, logits, out=None):

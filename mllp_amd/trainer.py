@@ -120,6 +120,7 @@ class LPTrainer:
         self.with_metrics = with_metrics
         self.tiled_copies = tiled_copies
         self._plans = {}
+        self._gen = 0                  # bumped at every library-side write of the parameters (LPBatch.train_step)
 
     def _plan(self, batch: LPBatch):
         key = batch.token          # unique per LPBatch for the life of the process (id() can be reused after a free)
@@ -150,6 +151,18 @@ class LPTrainer:
         """Drop the buffers (and the reference to the batch) kept for `batch`."""
         self._plans.pop(batch.token, None)
 
+    def _whole_step(self, p):
+        """single rank: forward + loss + backward + Adam in one library call (the tail of the fused path is one launch
+        that leaves the folded weights of the NEXT step in the batch's workspace: valid for the next step when it is on
+        the same batch and nobody else wrote the parameters -- this trainer owns them)"""
+        b = p["batch"]
+        inv = 1.0 / float(self.global_instances or b.n_inst)
+        b.train_step(self.params, self.opt.m, self.opt.v, self.opt.state, self.opt.eps, inv, p["logits"], p["loss"],
+                     p["grads"], param_gen=self._gen)
+        self._gen += 1
+        if self.with_metrics:
+            b.topm_metrics(p["logits"], p["metrics"])
+
     def _fwd_bwd(self, p):
         b = p["batch"]
         inv = 1.0 / float(self.global_instances or b.n_inst)
@@ -167,6 +180,7 @@ class LPTrainer:
         self._zero.zero_()
         allreduce_sum_(self._zero)
         self.opt.step(self._zero)
+        self._gen += 1
 
     def step(self, batch: LPBatch):
         """One optimizer step on `batch`; returns (loss, logits) device tensors (valid until the next step)."""
@@ -175,10 +189,13 @@ class LPTrainer:
         multi = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size() > 1 or os.environ.get("MLLP_BENCH_FORCE_DIST") == "1")
         if not p["graph"] or p["warm"] < 1:
-            self._fwd_bwd(p)
             if multi:
+                self._fwd_bwd(p)
                 allreduce_sum_(p["grads"])
-            self._opt(p)
+                self._opt(p)
+                self._gen += 1
+            else:
+                self._whole_step(p)
             p["warm"] += 1
             return p["loss"], p["logits"]
         if p["g_fwd"] is None:
@@ -195,6 +212,7 @@ class LPTrainer:
                     self._fwd_bwd(p)
                     self._opt(p)
             # capture does not execute: the captured step runs below
+        self._gen += 1
         p["g_fwd"].replay()
         if multi:
             allreduce_sum_(p["grads"])

@@ -1026,3 +1026,51 @@ def test_hip_trainer_two_ranks_equals_one_process(tmp_path, subset5, weights):
 def LPBatch_from(instances):
     from mllp_amd.graph import LPBatch as _B
     return _B.from_instances(list(instances))
+
+
+def test_train_step_equals_loss_step_plus_adam(LPBatch, subset5, weights):
+    """mllp_gnn_train_step (one library call per step; on the fused path its tail -- reduce, conv gradients, Adam, the
+    next step's folded weights -- is ONE launch with grid barriers) against mllp_gnn_loss_step + mllp_adam_step: the
+    same bits in parameters, moments, step counter, loss, logits and gradients over six steps, with the folded weights
+    reused (param_gen bookkeeping) and not reused, and after an in-place change of the parameters in between."""
+    from mllp_amd.graph import adam_step
+    flat, sd, flat_gpu = weights
+
+    def fresh():
+        p = flat_gpu.clone()
+        return p, torch.zeros_like(p), torch.zeros_like(p), torch.tensor([0.0, 1e-3, 0.9, 0.999], device="cuda")
+
+    b = LPBatch.from_instances(subset5)
+    p0, m0, v0, s0 = fresh()
+    ref = []
+    for k in range(6):
+        if k == 3:
+            p0.mul_(1.0001)                                       # somebody else writes the parameters
+        loss, logits, grads = b.loss_step(p0)
+        adam_step(p0, grads, m0, v0, s0, 1e-8)
+        ref.append((loss.clone(), logits.clone(), grads.clone(), p0.clone(), m0.clone(), v0.clone(), s0.clone()))
+    for reuse in (True, False):
+        b2 = LPBatch.from_instances(subset5)
+        p1, m1, v1, s1 = fresh()
+        gen = 0
+        for k in range(6):
+            if k == 3:
+                p1.mul_(1.0001)                                   # (bumps the tensor's version: the folds are stale)
+            loss, logits, grads = b2.train_step(p1, m1, v1, s1, 1e-8, param_gen=gen if reuse else None)
+            gen += 1
+            if reuse and k not in (0, 3):
+                assert b2._folded is not None
+            for got, want, what in zip((loss, logits, grads, p1, m1, v1, s1), ref[k],
+                                       ("loss", "logits", "grads", "params", "exp_avg", "exp_avg_sq", "state")):
+                assert torch.equal(got, want), (what, k, reuse)
+    # a forward with other parameters in between overwrites the folds: the next train_step must fold again
+    b3 = LPBatch.from_instances(subset5)
+    p2, m2, v2, s2 = fresh()
+    b3.train_step(p2, m2, v2, s2, 1e-8, param_gen=0)
+    b3.forward(flat_gpu * 0.5)
+    assert b3._folded is None
+    loss, logits, grads = b3.train_step(p2, m2, v2, s2, 1e-8, param_gen=1)
+    p3, m3, v3, s3 = fresh()
+    b.loss_step(p3); adam_step(p3, b.loss_step(p3)[2], m3, v3, s3, 1e-8)
+    want = b.loss_step(p3)
+    assert torch.equal(logits, want[1]) and torch.equal(grads, want[2])

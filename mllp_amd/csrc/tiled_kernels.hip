@@ -492,7 +492,12 @@ __global__ __launch_bounds__(T_THREADS) void fwd16_tiled_kernel(TiledDev t, FwdT
                             z.x *= sc; z.y *= sc; z.z *= sc; z.w *= sc;
                             m = mn;
                         }
-                        const float p0 = exp_acc_t(d0 - m), p1 = exp_acc_t(d1 - m);
+                        // the logits are the same in the four lanes of the quad: lanes 0, 2 take the exponential of the
+                        // first entry, lanes 1, 3 of the second, and share them by DPP (the exponential is the most
+                        // expensive operation of the walk; same arithmetic per value, two instead of four per lane-pair)
+                        const float pmine = exp_acc_t(((part & 1) ? d1 : d0) - m);
+                        const float p0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pmine), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
+                        const float p1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pmine), 0xF5, 0xF, 0xF, true));   // quad_perm [1,1,3,3]
                         L += p0 + p1;
                         u = fmaf(p0, a0, fmaf(p1, a1, u));
                         fma4(p0, x0, z);

@@ -585,7 +585,10 @@ def synthetic_batch(n_inst=256, m=10000, n=20000, mean_row_nnz=200.0, seed=1234,
         gcols = (cols + ((c0 + inst_of_row) * n).to(torch.int32)[:, None])[keep]
         vals = torch.randn(gcols.numel(), device=device, generator=g)
         rows = torch.repeat_interleave(torch.arange(k * m, device=device), cnt)
-        nrm = torch.zeros(k * m, device=device).index_add_(0, rows, vals * vals).sqrt_().clamp_(min=1e-12)
+        # row 2-norms by a per-row sequential reduction (rows are contiguous runs of `vals`): index_add_ uses floating-
+        # point atomics and cumsum a decoupled look-back scan -- either makes the last bits of the matrix change from run
+        # to run (tools/determinism_stream.py)
+        nrm = torch.segment_reduce(vals * vals, "sum", lengths=cnt, unsafe=True).sqrt_().clamp_(min=1e-12)
         vals = vals / nrm[rows]
         ptr = torch.cumsum(cnt, 0) + nnz_off
         nnz_off = int(ptr[-1])

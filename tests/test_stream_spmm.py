@@ -181,8 +181,11 @@ def test_streamed_spmm_at_32M_nonzeros(LPBatch):
     Y, Yt = sb.spmm(H), sb.spmm(G, transpose=True)
     close(Y.cpu().numpy(), ref.cpu().numpy(), 2e-6, "A H, streamed vs generic, 34 M nonzeros")
     close(Yt.cpu().numpy(), ref_t.cpu().numpy(), 2e-6, "At G, streamed vs generic, 34 M nonzeros")
+    # (2.7 M products of both signs cancel down to a sum of a few hundred: the fp32 rounding of the elements of Y and Yt,
+    # ~1e-7 relative each, adds up to ~1e-6 of that SUM; 5e-6 leaves room for the summation order, which the element-wise
+    # checks above do not depend on)
     lhs, rhs = float((Y.double() * G.double()).sum()), float((H.double() * Yt.double()).sum())
-    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0)
+    assert abs(lhs - rhs) <= 5e-6 * max(abs(lhs), abs(rhs), 1.0)
 
 
 def test_streamed_copy_argument_errors(LPBatch):

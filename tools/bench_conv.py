@@ -5,6 +5,9 @@ import os, sys
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("MLLP_LIB"):              # experiments: a variant build of the library
+    from mllp_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", os.environ["MLLP_LIB"])
 from mllp_amd.graph import synthetic_batch
 from mllp_amd.model import GNNModel, set_seed
 

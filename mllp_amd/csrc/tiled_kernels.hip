@@ -686,6 +686,27 @@ __global__ __launch_bounds__(T_THREADS) void bwdsrc16_tiled_kernel(TiledDev t, B
         fma4(alpha, gv, acc);
         fma4(dl, qp, acc);
     };
+    // two nonzeros at once: the logits are the same in the four lanes of a quad, so lanes 0, 2 take the exponential of the
+    // first and lanes 1, 3 of the second and share them by DPP (same values, same order of the accumulation as two edge() calls)
+    auto edge2 = [&](int off0, float av0, int off1, float av1, const float4& xj, float4& acc) {
+        const float4* r0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Rs) + off0);
+        const float4* r1 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Rs) + off1);
+        const float4 qp0 = r0[part], gv0 = r0[4 + part], s0 = r0[8];
+        const float4 qp1 = r1[part], gv1 = r1[4 + part], s1 = r1[8];
+        const float cc0 = reinterpret_cast<const float*>(r0)[36], cc1 = reinterpret_cast<const float*>(r1)[36];
+        const float l0 = fmaf(av0, s0.x, quad_sum4(dot4(qp0, xj)));
+        const float l1 = fmaf(av1, s1.x, quad_sum4(dot4(qp1, xj)));
+        const float em = exp_acc_t((part & 1) ? l1 - s1.y : l0 - s0.y);
+        const float e0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(em), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
+        const float e1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(em), 0xF5, 0xF, 0xF, true));   // quad_perm [1,1,3,3]
+        const float alpha0 = e0 * s0.z, alpha1 = e1 * s1.z;
+        const float dl0 = alpha0 * (quad_sum4(dot4(gv0, xj)) + fmaf(av0, s0.w, cc0));
+        const float dl1 = alpha1 * (quad_sum4(dot4(gv1, xj)) + fmaf(av1, s1.w, cc1));
+        fma4(alpha0, gv0, acc);
+        fma4(dl0, qp0, acc);
+        fma4(alpha1, gv1, acc);
+        fma4(dl1, qp1, acc);
+    };
     auto walk = [&](int cur_seg0, int cur_len) {
         for (int w0 = 0; w0 < cur_len; w0 += S_ECAP) {
             if (w0 > 0) {   // rare: segment longer than one window
@@ -707,8 +728,7 @@ __global__ __launch_bounds__(T_THREADS) void bwdsrc16_tiled_kernel(TiledDev t, B
                     const int pe_ = e - w0;
                     for (; p + 1 < pe_; p += 2) {      // two entries per pass: independent LDS reads and dot products
                         const int2 e0 = Es[p], e1 = Es[p + 1];
-                        edge(e0.x, __int_as_float(e0.y), xj, acc);
-                        edge(e1.x, __int_as_float(e1.y), xj, acc);
+                        edge2(e0.x, __int_as_float(e0.y), e1.x, __int_as_float(e1.y), xj, acc);
                     }
                     if (p < pe_) {
                         const int2 e0 = Es[p];

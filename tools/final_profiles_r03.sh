@@ -9,6 +9,8 @@ step bench_plain 900 python3 bench.py
 step bench_prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_bench -- python3 bench.py --no-cpu-baseline
 # the raw kernel trace (every torch kernel of the tiled-copy builder included) exceeds what gpurun copies back: keep the summary
 python3 tools/summarize_rocprof.py gpurun_out/final/prof_bench gpurun_out/final/kernel_stats.md > /dev/null; rm -rf gpurun_out/final/prof_bench
+step netlib_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_netlib -- python3 tools/profile_step.py netlib 30
+python3 tools/summarize_rocprof.py gpurun_out/final/prof_netlib gpurun_out/final/netlib_kernel_stats.md > /dev/null; rm -rf gpurun_out/final/prof_netlib
 fi
 if [ $part = a ]; then exit 0; fi
 step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_fetch -- python3 tools/profile_stream.py 256 3

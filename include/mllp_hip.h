@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLLP_ABI_VERSION 1
+#define MLLP_ABI_VERSION 2 /* 2: streamed SpMM copy, device-built tiled copies, mllp_gnn_train_step, mllp_graph_invalidate_inputs */
 #define MLLP_FEAT 16
 #define MLLP_NUM_PARAMS 4721 /* GNNModel.state_dict(), SURVEY.md appendix A.2 */
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmllp_hip.so")
 HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "mllp_hip.h"))
 
 NUM_PARAMS = 4721
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MllpError(RuntimeError):

@@ -293,6 +293,8 @@ class LPBatch:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if arrays is None and builder == "device":
+            if self.nnz == 0:
+                return None                      # (nothing to re-block: the generic sweeps handle the empty matrix)
             rc = L.mllp_graph_build_tiled(self._h, int(transpose), int(variant), _lib.current_stream())
             torch.cuda.synchronize()
             self.tiled_build_s = getattr(self, "tiled_build_s", 0.0) + time.perf_counter() - t0

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
@@ -44,3 +46,32 @@ def test_launcher_decisions(monkeypatch):
     assert b.maybe_launch(a2, ["--gpus", "2"]) is None                     # already a rank of a 2-rank job
     a8 = b.parse(["--gpus", "8"])
     assert b.maybe_launch(a8, ["--gpus", "8"]) == 2                        # launched with the wrong world size: refuse
+
+
+@pytest.mark.gpu
+def test_bench_json_contract_on_the_gpu():
+    """`python bench.py` end to end at a reduced size (17 synthetic instances = the throughput regime, 3 timed steps):
+    exactly one JSON line with the contract's keys, a roofline object for the streamed SpMM with frac = achieved / peak,
+    parity figures inside it, and a cpu_baseline object (one epoch's worth is enough here)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--synthetic-instances", "17", "--synthetic-steps", "2", "--spmm-reps", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "spmm_stream_kernel" in rf["kernel"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
+    k0 = rf["kernels"][0]
+    assert abs(k0["GBps"] - k0["alg_bytes"] / k0["ms"] / 1e6) < 1e-6 * k0["GBps"] and k0["max_rel_diff_vs_generic"] < 2e-6
+    assert d["synthetic"]["logits_max_rel_diff_tiled_vs_generic"] < 5e-6 and d["synthetic"]["tiled_build_s"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    assert d["value"] > 100 * cb["value"]

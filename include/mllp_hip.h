@@ -70,6 +70,14 @@ int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, const int64_t*
 /* From device arrays that already hold the batch in global ids, both orientations (CSR of A:
  * rows = constraints; CSR of A^T: rows = variables, row ids ascending within a column).  The
  * arrays are copied.  inst_ptr_m / inst_ptr_n are HOST arrays of n_inst + 1 offsets.           */
+/* CSR(A) -> CSR(A^T) on the device (counting + scatter + per-column ordering by row id: the one stable transposition,
+ * whatever order the scatter's atomics produced; mllp_amd/csrc/transpose.hip): the second orientation that
+ * mllp_graph_create_device wants, for batches that were generated or loaded on the GPU.  All arrays are caller-owned
+ * device memory: d_ptr [n_rows + 1], d_idx / d_val [nnz] (column ids ascending inside a row), outputs d_t_ptr
+ * [n_cols + 1], d_t_idx / d_t_val [nnz].  Allocates scratch and synchronises `stream` (not a launch function).    */
+int mllp_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* d_ptr, const int32_t* d_idx,
+                              const float* d_val, int32_t* d_t_ptr, int32_t* d_t_idx, float* d_t_val, void* stream);
+
 int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_m, const int64_t* inst_ptr_n,
                              int64_t nnz,
                              const int32_t* d_csr_ptr, const int32_t* d_csr_idx, const float* d_csr_val,

@@ -39,6 +39,8 @@ _PROTOTYPES = {
     "mllp_graph_drop_spmm_copy": (c_int, [c_void_p, c_int]),
     "mllp_graph_spmm_copy_info": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "mllp_graph_export_spmm_copy": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64]),
+    "mllp_csr_transpose_device": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
     "mllp_graph_build_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "mllp_graph_tiled_info": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64)]),
     "mllp_graph_export_tiled": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),

@@ -241,23 +241,33 @@ class LPBatch:
 
     @staticmethod
     def from_device_csr(inst_m, inst_n, csr_ptr, csr_idx, csr_val, x1, x2, labels, tier_wave=0, tier_block=0,
-                        names=None) -> "LPBatch":
-        """Batch from device CSR arrays in global ids (int32 ptr/idx, fp32 values).  The transposed
-        orientation is built here with one stable device sort (torch -> rocPRIM): plumbing, done once."""
+                        names=None, transpose="device") -> "LPBatch":
+        """Batch from device CSR arrays in global ids (int32 ptr/idx, fp32 values).  The transposed orientation is
+        built by the library (`mllp_csr_transpose_device`: counting, scatter, per-column ordering) -- or, with
+        transpose="torch", by one stable device sort (the reference the tests compare with)."""
         L = _lib.lib()
         import time
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         M, N, nnz = int(sum(inst_m)), int(sum(inst_n)), int(csr_idx.numel())
-        rows = torch.repeat_interleave(torch.arange(M, device=csr_idx.device, dtype=torch.int32),
-                                       (csr_ptr[1:] - csr_ptr[:-1]).long())
-        order = torch.sort(csr_idx.long(), stable=True)[1]        # stable: row ids ascend inside a column
-        csc_idx = rows[order].contiguous()
-        csc_val = csr_val[order].contiguous()
-        counts = torch.bincount(csr_idx.long(), minlength=N)
-        csc_ptr = torch.zeros(N + 1, dtype=torch.int32, device=csr_idx.device)
-        csc_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        del rows, order, counts
+        if transpose == "torch":      # reference for the tests: one stable sort by column
+            rows = torch.repeat_interleave(torch.arange(M, device=csr_idx.device, dtype=torch.int32),
+                                           (csr_ptr[1:] - csr_ptr[:-1]).long())
+            order = torch.sort(csr_idx.long(), stable=True)[1]        # stable: row ids ascend inside a column
+            csc_idx = rows[order].contiguous()
+            csc_val = csr_val[order].contiguous()
+            counts = torch.bincount(csr_idx.long(), minlength=N)
+            csc_ptr = torch.zeros(N + 1, dtype=torch.int32, device=csr_idx.device)
+            csc_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            del rows, order, counts
+        else:                         # the library's transposition kernels (transpose.hip)
+            dev = csr_idx.device
+            csc_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            csc_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+            csc_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+            _lib.check(L.mllp_csr_transpose_device(M, N, nnz, _lib.ptr(csr_ptr), _lib.ptr(csr_idx), _lib.ptr(csr_val),
+                                                   _lib.ptr(csc_ptr), _lib.ptr(csc_idx), _lib.ptr(csc_val),
+                                                   _lib.current_stream()))
         pm = np.concatenate([[0], np.cumsum(inst_m)]).astype(np.int64)
         pn = np.concatenate([[0], np.cumsum(inst_n)]).astype(np.int64)
         h = c_void_p()

@@ -1074,3 +1074,59 @@ def test_train_step_equals_loss_step_plus_adam(LPBatch, subset5, weights):
     b.loss_step(p3); adam_step(p3, b.loss_step(p3)[2], m3, v3, s3, 1e-8)
     want = b.loss_step(p3)
     assert torch.equal(logits, want[1]) and torch.equal(grads, want[2])
+
+
+def test_device_transposition_equals_stable_sort():
+    """mllp_csr_transpose_device (transpose.hip: integer-atomic counting and scatter, then every column ordered by row id)
+    against the stable sort by column it replaces: row pointers, row ids and values bit-identical -- on a synthetic batch,
+    on a matrix with empty rows / empty columns / a dense column of 5 000 entries (the workgroup path for columns longer
+    than one wavefront's LDS window) and a dense row, on the empty matrix; and the batches built either way agree."""
+    from ctypes import c_void_p
+    from mllp_amd import _lib
+    from mllp_amd.graph import synthetic_batch
+
+    def torch_transpose(ptr, idx, val, M, N):
+        rows = torch.repeat_interleave(torch.arange(M, device="cuda", dtype=torch.int32), (ptr[1:] - ptr[:-1]).long())
+        order = torch.sort(idx.long(), stable=True)[1]
+        tptr = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+        tptr[1:] = torch.cumsum(torch.bincount(idx.long(), minlength=N), 0).to(torch.int32)
+        return tptr, rows[order].contiguous(), val[order].contiguous()
+
+    def lib_transpose(ptr, idx, val, M, N):
+        nnz = int(idx.numel())
+        tptr = torch.empty(N + 1, dtype=torch.int32, device="cuda")
+        tidx = torch.full((max(nnz, 1),), -7, dtype=torch.int32, device="cuda")
+        tval = torch.full((max(nnz, 1),), float("nan"), device="cuda")
+        _lib.check(_lib.lib().mllp_csr_transpose_device(M, N, nnz, _lib.ptr(ptr), _lib.ptr(idx) if nnz else c_void_p(0),
+                                                        _lib.ptr(val) if nnz else c_void_p(0), _lib.ptr(tptr), _lib.ptr(tidx),
+                                                        _lib.ptr(tval), _lib.current_stream()))
+        return tptr, tidx[:nnz], tval[:nnz]
+
+    rng = np.random.default_rng(3)
+    M, N = 6000, 2100
+    rows = []
+    for r in range(M):
+        k = 0 if r % 7 == 3 else int(rng.integers(1, 9))
+        c = set(rng.choice(N - 100, size=k, replace=False).tolist())      # (the last 100 columns stay empty, except ...)
+        if r < 5000:
+            c.add(N - 1)                                                  # ... a dense column of 5 000 entries
+        rows.append(np.sort(np.fromiter(c, dtype=np.int64)))
+    rows[11] = np.arange(0, N - 100, 1)                                   # a dense row
+    ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    idx = np.concatenate(rows).astype(np.int32)
+    cases = [(torch.tensor(ptr, device="cuda"), torch.tensor(idx, device="cuda"),
+              torch.tensor(rng.standard_normal(len(idx)).astype(np.float32), device="cuda"), M, N)]
+    sb = synthetic_batch(n_inst=3, m=700, n=1300, mean_row_nnz=20.0, seed=5, chunk=1)
+    cases.append((*sb._device_orientation(False), sb.M, sb.N))
+    cases.append((torch.zeros(5, dtype=torch.int32, device="cuda"), torch.zeros(0, dtype=torch.int32, device="cuda"),
+                  torch.zeros(0, device="cuda"), 4, 6))
+    for p, i, v, m, n in cases:
+        want, got = torch_transpose(p, i, v, m, n), lib_transpose(p, i, v, m, n)
+        for a, b, what in zip(got, want, ("ptr", "idx", "val")):
+            assert torch.equal(a, b), (what, m, n)
+        again = lib_transpose(p, i, v, m, n)                               # whatever order the atomics took this time
+        assert all(torch.equal(a, b) for a, b in zip(again, got))
+    # the two ways to build a batch give the same graph arrays
+    a = synthetic_batch(n_inst=2, m=300, n=500, mean_row_nnz=10.0, seed=9, chunk=1)
+    for k in range(3, 6):
+        np.testing.assert_array_equal(a.export(k), np.asarray(torch_transpose(*a._device_orientation(False), a.M, a.N)[k - 3].cpu()))

@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "FETCH_SIZE" "WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" ; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_fused/pass$i -- python3 tools/profile_step.py netlib 3 > gpurun_out/pmc_fused/pass$i.log 2>&1
-  rc=$?; echo "pass$i rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
+  rc=$?; echo "pass$i rc=$rc"; if [ $rc -ne 0 ]; then tail -5 gpurun_out/pmc_fused/pass$i.log; exit $rc; fi
 done
-python3 tools/summarize_pmc.py gpurun_out/pmc_fused fused_ > gpurun_out/r02_fused_pmc.txt 2>&1
+python3 tools/summarize_pmc.py gpurun_out/pmc_fused fused_ > gpurun_out/fused_pmc.txt 2>&1
 rm -rf gpurun_out/pmc_fused/pass*/

@@ -294,6 +294,7 @@ extern "C" int mllp_graph_set_path(mllp_graph_t* g, int path) {
         if (rc) return rc;
     }
     g->path = path;
+    g->folded_ws = g->folded_params = nullptr;      // the other path does not maintain the folded weights
     return MLLP_OK;
 }
 
@@ -417,6 +418,7 @@ extern "C" int mllp_gnn_forward(const mllp_graph_t* g, const float* d_params, co
     mllp_graph* gm = const_cast<mllp_graph*>(g);          // (bookkeeping only: which path wrote which workspace)
     gm->ws_ptr = d_ws;
     gm->ws_path = use_fused(g) ? 1 : 0;
+    gm->folded_ws = gm->folded_params = nullptr;
     if (use_fused(g))
         return fused_forward(gm, fused_model(g, d_params, d_x1, d_x2, w, nullptr, 0.0f, d_logits), 1, s);
     if ((rc = model_forward_body(g, d_params, d_x1, d_x2, w, s))) return rc;
@@ -454,6 +456,7 @@ extern "C" int mllp_gnn_loss_step(const mllp_graph_t* g, const float* d_params, 
     hipStream_t s = (hipStream_t)stream;
     ModelWs w = model_ws(g, (float*)d_ws);
     int rc;
+    const_cast<mllp_graph*>(g)->folded_ws = const_cast<mllp_graph*>(g)->folded_params = nullptr;
     if (use_fused(g)) {
         const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, d_labels, inv_batch, d_logits);
         if ((rc = fused_forward(const_cast<mllp_graph*>(g), m, 2, s))) return rc;
@@ -476,13 +479,22 @@ extern "C" int mllp_gnn_train_step(const mllp_graph_t* g, float* d_params, const
     REQUIRE((flags & ~1) == 0, "flags: bit 0 = the folded weights in the workspace are current");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    mllp_graph* gm = const_cast<mllp_graph*>(g);
     if (use_fused(g)) {
         ModelWs w = model_ws(g, (float*)d_ws);
         const FusedModel m = fused_model(g, d_params, d_x1, d_x2, w, d_labels, inv_batch, d_logits);
-        if ((rc = fused_forward(const_cast<mllp_graph*>(g), m, 2, s, (flags & 1) != 0))) return rc;
+        // bit 0 is the caller's claim that the parameters are unchanged since the last call; the library checks on its
+        // side that the last whole-model call on this graph was a fused train_step on this workspace and these parameters
+        const bool skip = (flags & 1) != 0 && gm->folded_ws == d_ws && gm->folded_params == d_params;
+        gm->folded_ws = gm->folded_params = nullptr;
+        if ((rc = fused_forward(gm, m, 2, s, skip))) return rc;
         const FusedAdam a = {d_params, d_exp_avg, d_exp_avg_sq, d_state, eps, (int)MLLP_NUM_PARAMS};
-        return fused_backward(g, m, true, d_grads, d_loss, s, &a);
+        if ((rc = fused_backward(g, m, true, d_grads, d_loss, s, &a))) return rc;
+        gm->folded_ws = d_ws;
+        gm->folded_params = d_params;
+        return MLLP_OK;
     }
+    gm->folded_ws = gm->folded_params = nullptr;
     // throughput regime: the same two calls a caller would make (the tail is 0.1 % of such a step)
     if ((rc = mllp_gnn_loss_step(g, d_params, d_x1, d_x2, d_labels, inv_batch, d_ws, d_logits, d_loss, d_grads, stream)))
         return rc;

@@ -128,6 +128,11 @@ struct mllp_graph {
     const void* bound_labels = nullptr;
     int ws_path = -1;            // which whole-model path wrote the workspace last: 0 generic / tiled, 1 fused (backward checks it)
     const void* ws_ptr = nullptr;
+    // which {workspace, parameters} hold the folded weights that fused_tail_kernel left behind for the NEXT step
+    // (mllp_gnn_train_step flags bit 0 is honoured only when both match; every other whole-model call, a path switch
+    // and the generic branch of train_step clear the record)
+    const void* folded_ws = nullptr;
+    const void* folded_params = nullptr;
     // second stream + events: the two convs of a layer (one per orientation) and the single-workgroup
     // finalize kernels run beside the main stream (fork/join by events, also under hipGraph capture)
     hipStream_t aux = nullptr;

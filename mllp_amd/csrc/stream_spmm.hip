@@ -101,7 +101,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // site here (+ 2 scalar for the guard and the hook's conditional load), 43 in the compiler-scheduled version.
 // tools/check_asm_reads.py verifies on the generated assembly, at every build, that no compiler-generated instruction
 // names a reserved register and that no VALU result is read by a DPP instruction of the asm within two instructions.
-#ifdef MLLP_SK_WAIT8      // (experiment: timing of a deeper pipeline; the results are wrong)
+#if defined(MLLP_TIMING_BUILD) && defined(MLLP_SK_WAIT8)      // (timing build only: a deeper pipeline; the results are wrong)
 #define SK_WAITN "s_waitcnt lgkmcnt(8)\n\t"
 #else
 #define SK_WAITN "s_waitcnt lgkmcnt(4)\n\t"

@@ -214,6 +214,7 @@ class LPBatch:
     def set_path(self, path):
         """0 = by size, 1 = generic / LDS-tiled sweeps, 2 = fused latency-regime kernels (whole-model calls only)."""
         _lib.check(_lib.lib().mllp_graph_set_path(self._h, int(path)))
+        self._folded = None
         return self
 
     # ---- construction ------------------------------------------------------------------------

@@ -1074,6 +1074,33 @@ def test_train_step_equals_loss_step_plus_adam(LPBatch, subset5, weights):
     b.loss_step(p3); adam_step(p3, b.loss_step(p3)[2], m3, v3, s3, 1e-8)
     want = b.loss_step(p3)
     assert torch.equal(logits, want[1]) and torch.equal(grads, want[2])
+    # a path switch in between: the generic branch leaves only pre-Adam folds behind, so a fused train_step
+    # after it must fold again -- in the wrapper (set_path drops _folded) AND in the library, which ignores flags bit 0
+    # unless its own record says the last call was a fused train_step on this workspace and these parameters
+    from ctypes import c_void_p
+    from mllp_amd import _lib
+    for raw_flag in (False, True):
+        b4 = LPBatch.from_instances(subset5)
+        p4, m4, v4, s4 = fresh()
+        b4.set_path(1)
+        b4.train_step(p4, m4, v4, s4, 1e-8, param_gen=0)
+        b4.set_path(2)
+        assert b4._folded is None
+        if raw_flag:        # a caller of the C ABI that claims "folded" after the generic step
+            logits4 = torch.empty(b4.N, device="cuda"); loss4 = torch.empty(1, device="cuda")
+            grads4 = torch.empty(_lib.NUM_PARAMS, device="cuda")
+            _lib.check(_lib.lib().mllp_gnn_train_step(b4._h, _lib.ptr(p4), _lib.ptr(b4.x1), _lib.ptr(b4.x2), _lib.ptr(b4.labels),
+                                                      1.0 / b4.n_inst, _lib.ptr(b4.workspace()), _lib.ptr(logits4),
+                                                      _lib.ptr(loss4), _lib.ptr(grads4), _lib.ptr(m4), _lib.ptr(v4),
+                                                      _lib.ptr(s4), 1e-8, 1, _lib.current_stream()))
+        else:
+            loss4, logits4, grads4 = b4.train_step(p4, m4, v4, s4, 1e-8, param_gen=1)
+        # reference: two plain steps (generic, then fused) with loss_step + adam_step
+        b5 = LPBatch.from_instances(subset5)
+        p5, m5, v5, s5 = fresh()
+        b5.set_path(1); adam_step(p5, b5.loss_step(p5)[2], m5, v5, s5, 1e-8)
+        b5.set_path(2); l5, z5, g5 = b5.loss_step(p5); adam_step(p5, g5, m5, v5, s5, 1e-8)
+        assert torch.equal(logits4, z5) and torch.equal(grads4, g5) and torch.equal(p4, p5), raw_flag
 
 
 def test_device_transposition_equals_stable_sort():

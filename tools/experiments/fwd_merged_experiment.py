@@ -1,12 +1,14 @@
+"""Experiment script (NOT a test; run by hand on a GPU box): three forward launches merged into one persistent launch."""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
 if os.environ.get("MLLP_LIB"):
     from mllp_amd import _lib
-    _lib.LIB_PATH = os.path.join("/root/repo/mllp_amd/csrc", os.environ["MLLP_LIB"])
+    _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", os.environ["MLLP_LIB"])
 from mllp_amd.data import load_packed
 from mllp_amd.graph import LPBatch
 from mllp_amd.trainer import LPTrainer
-gold = np.load("/root/repo/tests/golden/subset5.npz", allow_pickle=False)
+gold = np.load(os.path.join(ROOT, "tests", "golden", "subset5.npz"), allow_pickle=False)
 params = torch.tensor(gold["weights_flat"], dtype=torch.float32, device="cuda")
 b5 = LPBatch.from_instances(load_packed(["adlittle.mps","afiro.mps","blend.mps","kb2.mps","sc50a.mps"]))
 names=[str(n) for n in gold["names"]]

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLLP_ABI_VERSION 2 /* 2: streamed SpMM copy, device-built tiled copies, mllp_gnn_train_step, mllp_graph_invalidate_inputs */
+#define MLLP_ABI_VERSION 3 /* 2: streamed SpMM copy, device-built tiled copies, mllp_gnn_train_step, mllp_graph_invalidate_inputs; 3: streamed copies of the attention sweeps (mllp_graph_*_stream_copy) */
 #define MLLP_FEAT 16
 #define MLLP_NUM_PARAMS 4721 /* GNNModel.state_dict(), SURVEY.md appendix A.2 */
 
@@ -146,6 +146,25 @@ int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* 
 int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose);
 int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]);
 int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which, void* host_dst, int64_t capacity_bytes);
+
+/* Streamed copies for the ATTENTION sweeps of the throughput regime (round 4; mllp_amd/csrc/stream_attn.hip): the same
+ * layout and builders in other geometries, one library-owned copy per (orientation, geometry).  The four functions above
+ * are these with geom = 0.
+ *   geom 0  plain SpMM: 960-row tiles x 750-column blocks, four rows per quad (mllp_spmm_csr_f32)
+ *   geom 1  attention forward sweep of a 16-channel TransformerConv whose DESTINATIONS are the rows of this orientation
+ *           (transpose = 0: constraints, 1: variables): 480-row tiles x 720-column blocks, two rows per quad, 64-byte
+ *           staged items.  When present, mllp_tconv_fwd and the mllp_gnn_* calls of the generic / tiled path use it in
+ *           place of the LDS-tiled variant 1.
+ *   geom 2  source-major backward sweep (rows of this orientation = the conv's SOURCE nodes): 312-column blocks of the
+ *           160-byte destination records; replaces LDS-tiled variant 2.
+ *   geom 3  destination-major backward sweep (rows = the conv's destinations): 432-column blocks; replaces variant 4.
+ *   mllp_graph_stream_copy_info: info[0..5] as mllp_graph_spmm_copy_info; info[6] = row slots per tile | rows per quad
+ *          << 16 | bytes per staged item << 24; info[7] = columns per block | wavefronts << 16 | padding groups << 24. */
+int mllp_graph_build_stream_copy(mllp_graph_t* g, int transpose, int geom, int where, void* stream);
+int mllp_graph_drop_stream_copy(mllp_graph_t* g, int transpose, int geom);
+int mllp_graph_stream_copy_info(const mllp_graph_t* g, int transpose, int geom, int64_t info[8]);
+int mllp_graph_export_stream_copy(const mllp_graph_t* g, int transpose, int geom, int which, void* host_dst,
+                                  int64_t capacity_bytes);
 
 /* Optional LDS-tiled copy of one orientation for large batches (rows of ~100+ nonzeros): the nonzeros
  * re-blocked into row tiles x column blocks so that source rows are read from LDS instead of L2.

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmllp_hip.so")
 HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "mllp_hip.h"))
 
 NUM_PARAMS = 4721
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MllpError(RuntimeError):
@@ -39,6 +39,10 @@ _PROTOTYPES = {
     "mllp_graph_drop_spmm_copy": (c_int, [c_void_p, c_int]),
     "mllp_graph_spmm_copy_info": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "mllp_graph_export_spmm_copy": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64]),
+    "mllp_graph_build_stream_copy": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mllp_graph_drop_stream_copy": (c_int, [c_void_p, c_int, c_int]),
+    "mllp_graph_stream_copy_info": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64)]),
+    "mllp_graph_export_stream_copy": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),
     "mllp_csr_transpose_device": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
     "mllp_graph_build_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -219,8 +219,8 @@ extern "C" int mllp_graph_create_device(int64_t n_inst, const int64_t* inst_ptr_
 
 extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     if (!g) return MLLP_OK;
-    mllp::stream_copy_free(g->A.stream);
-    mllp::stream_copy_free(g->At.stream);
+    for (mllp::Orient* o : {&g->A, &g->At})
+        for (mllp::StreamCopy* sc : {&o->stream, &o->stream_attn, &o->stream_bsrc, &o->stream_bdst}) mllp::stream_copy_free(*sc);
     for (mllp::Orient* o : {&g->A, &g->At})
         for (mllp::Tiled* tl : {&o->tiled, &o->tiled_attn, &o->tiled_bsrc, &o->tiled_scalar, &o->tiled_bdst}) mllp::tiled_free(*tl);
     for (void* p : g->allocs) (void)hipFree(p);

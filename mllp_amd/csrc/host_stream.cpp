@@ -24,7 +24,9 @@ struct TileScan {
     std::vector<int> order;      // [nb * S_R] sorted position -> row (entries descending, ties by row)
 };
 
+template <class G>
 void scan_tile(const int* ptr, const int* idx, const std::vector<int>& tile_row, int t, TileScan& s) {
+    constexpr int S_R = G::R, S_CB = G::CB;
     const int64_t r0 = tile_row[t];
     const int rows = tile_row[t + 1] - tile_row[t];
     s.blocks.clear();
@@ -57,8 +59,9 @@ void scan_tile(const int* ptr, const int* idx, const std::vector<int>& tile_row,
     }
 }
 
+template <class G>
 inline int pass_steps(const TileScan& s, size_t bi, int bundle) {     // entries of the bundle's longest row
-    return s.cnt[bi * S_R + s.order[bi * S_R + S_BR * bundle]];
+    return s.cnt[bi * G::R + s.order[bi * G::R + G::BR * bundle]];
 }
 
 // one row of a team during the joint ordering
@@ -72,8 +75,10 @@ struct RowCur {
 // S .. S + n - 1.  The four rows of a team are ordered JOINTLY: at step p the row that chooses first rotates
 // with p; a row takes its most numerous remaining class (column mod 4; lowest class on ties) that no team mate has
 // taken in this step, or its most numerous class when all are taken.  Rows shorter than n keep the padding entries.
+template <class G>
 void fill_slot(const int* idx, const float* val, int blk, const TileScan& s, size_t bi, const int* rows, int64_t S,
                int slot, int* ent) {
+    constexpr int S_R = G::R, S_CB = G::CB, S_ROW_BYTES = G::ITEM;
     for (int tm = 0; tm < 4; ++tm) {
         RowCur rc[4];
         int maxlen = 0;
@@ -105,7 +110,7 @@ void fill_slot(const int* idx, const float* val, int blk, const TileScan& s, siz
                 used |= 1u << pick;
                 const int64_t step = S + p;
                 const int q = S_TEAMS[tm][i];
-                int* dst = ent + s_ent_index(step, q, slot);
+                int* dst = ent + G::ent_index(step, q, slot);
                 const unsigned o16 = (unsigned)(idx[c.beg + e] - blk * S_CB) * S_ROW_BYTES;
                 dst[0] = (step & 1) ? (int)(((unsigned)dst[0] & 0xffffu) | o16 << 16) : (int)(((unsigned)dst[0] & 0xffff0000u) | o16);
                 std::memcpy(&dst[1 + (step & 1)], &val[c.beg + e], 4);
@@ -130,7 +135,9 @@ void parallel_tiles(int n_tiles, unsigned nt, F f) {
 
 }  // namespace
 
-std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst) {
+template <class G>
+static std::vector<int> stream_tiles_t(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst) {
+    constexpr int S_RR = G::RR;
     std::vector<int> tr(1, 0);
     const int64_t one[2] = {0, n_dst};
     if (!seg_ptr) { seg_ptr = one; n_seg = 1; }
@@ -142,8 +149,11 @@ std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_
     return tr;
 }
 
-int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
-                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads) {
+template <class G>
+static int build_stream_t(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
+                          const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads) {
+    constexpr int S_R = G::R, S_NW = G::NW, S_P = G::P, S_GS = G::GS, S_K0 = G::K0, S_ENT = G::ENT, S_PAD_WORD = G::PAD_WORD,
+                  S_RQ = G::RQ, S_BR = G::BR;
     auto bad = [&](int code, const char* msg) {
         if (err) *err = msg;
         return code;
@@ -154,7 +164,7 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     if (n_dst >= ((int64_t)1 << 31) - 1) return bad(MLLP_ERANGE, "host_build_stream: too many rows");
     HostStream& o = *out;
     o = HostStream();
-    o.tile_row = host_stream_tiles(seg_ptr, n_seg, n_dst);
+    o.tile_row = stream_tiles_t<G>(seg_ptr, n_seg, n_dst);
     const int n_tiles = (int)o.tile_row.size() - 1;
     const unsigned nt = max_threads ? max_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     o.n_tiles = n_tiles;
@@ -165,11 +175,11 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     std::vector<TileScan> scans(nt);
     parallel_tiles(n_tiles, nt, [&](int t, unsigned k) {
         TileScan& s = scans[k];
-        scan_tile(ptr, idx, o.tile_row, t, s);
+        scan_tile<G>(ptr, idx, o.tile_row, t, s);
         o.tile_blk[t + 1] = (int)s.blocks.size();
         for (size_t bi = 0; bi < s.blocks.size(); ++bi)
             for (int w = 0; w < S_NW; ++w)
-                for (int j = 0; j < S_P; ++j) steps[(size_t)t * S_NW + w] += pass_steps(s, bi, s_bundle(w, j));
+                for (int j = 0; j < S_P; ++j) steps[(size_t)t * S_NW + w] += pass_steps<G>(s, bi, G::bundle(w, j));
     });
     int64_t n_tb = 0;
     for (int t = 0; t < n_tiles; ++t) {
@@ -200,7 +210,7 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     // pass 2: records and entries
     parallel_tiles(n_tiles, nt, [&](int t, unsigned k) {
         TileScan& s = scans[k];
-        scan_tile(ptr, idx, o.tile_row, t, s);
+        scan_tile<G>(ptr, idx, o.tile_row, t, s);
         const int tb0 = o.tile_blk[t];
         int64_t cur[S_NW];
         for (int w = 0; w < S_NW; ++w) cur[w] = base[(size_t)t * S_NW + w] * S_GS;
@@ -213,13 +223,13 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
                 int* rows = &o.rows[(((size_t)(tb0 + bi) * S_NW + w) * 16) * 4];
                 int64_t S = cur[w];
                 for (int j = 0; j < S_P; ++j) {
-                    const int p = s_bundle(w, j);
-                    n[j] = pass_steps(s, bi, p);
+                    const int p = G::bundle(w, j);
+                    n[j] = pass_steps<G>(s, bi, p);
                     for (int q = 0; q < 16; ++q)
                         for (int r = 0; r < S_RQ; ++r)
                             rows[q * 4 + 2 * j + (r >> 1)] |= ord[S_BR * p + 16 * r + q] << (16 * (r & 1));
                     for (int slot = 0; slot < S_RQ; ++slot)
-                        fill_slot(idx, val, blk, s, bi, ord + S_BR * p + 16 * slot, S, slot, o.ent.data());
+                        fill_slot<G>(idx, val, blk, s, bi, ord + S_BR * p + 16 * slot, S, slot, o.ent.data());
                     S += n[j];
                 }
                 int* hdr = &o.hdr[((size_t)(tb0 + bi) * S_NW + w) * 4];
@@ -235,7 +245,9 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
     return MLLP_OK;
 }
 
-int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y) {
+template <class G>
+static int64_t walk_stream_t(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y) {
+    constexpr int S_NW = G::NW, S_P = G::P, S_GS = G::GS, S_RQ = G::RQ, S_CB = G::CB, S_ZERO_OFF = G::ZERO_OFF, S_ROW_BYTES = G::ITEM;
     int64_t real = 0;
     for (int t = 0; t < s.n_tiles; ++t) {
         for (int tb = s.tile_blk[t]; tb < s.tile_blk[t + 1]; ++tb) {
@@ -251,7 +263,7 @@ int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, cons
                         for (int64_t st = a; st < b; ++st) {
                             if (st / S_GS >= s.n_groups) return -1;
                             for (int slot = 0; slot < S_RQ; ++slot) {
-                                const int* g = &s.ent[(size_t)s_ent_index(st, q, slot)];
+                                const int* g = &s.ent[(size_t)G::ent_index(st, q, slot)];
                                 const int off = (int)(((unsigned)g[0] >> ((st & 1) * 16)) & 0xffffu);
                                 const int* e = g + (st & 1);         // e[1] = value bits
                                 if (off == S_ZERO_OFF) {
@@ -276,6 +288,33 @@ int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, cons
         }
     }
     return real;
+}
+
+// ---- public entry points: geometry by id (stream_layout.h::STREAM_GEOM_*) ---------------------------------------
+#define MLLP_GEOM_DISPATCH(geom, CALL)                       \
+    switch (geom) {                                          \
+        case STREAM_GEOM_SPMM: { using G = SpmmGeom; CALL; } \
+        case STREAM_GEOM_ATTN: { using G = AttnGeom; CALL; } \
+        case STREAM_GEOM_BSRC: { using G = BsrcGeom; CALL; } \
+        case STREAM_GEOM_BDST: { using G = BdstGeom; CALL; } \
+        default: break;                                      \
+    }
+
+std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst, int geom) {
+    MLLP_GEOM_DISPATCH(geom, return stream_tiles_t<G>(seg_ptr, n_seg, n_dst))
+    return std::vector<int>();
+}
+
+int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
+                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads, int geom) {
+    MLLP_GEOM_DISPATCH(geom, return build_stream_t<G>(ptr, idx, val, n_dst, n_src, seg_ptr, n_seg, out, err, max_threads))
+    if (err) *err = "host_build_stream: unknown geometry";
+    return MLLP_EINVAL;
+}
+
+int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y, int geom) {
+    MLLP_GEOM_DISPATCH(geom, return walk_stream_t<G>(s, n_dst, n_src, H, Y))
+    return -1;
 }
 
 }  // namespace mllp

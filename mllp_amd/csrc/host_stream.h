@@ -25,15 +25,17 @@ struct HostStream {
 
 // Row tiles of at most S_RR rows that never cross a segment boundary (seg_ptr: [n_seg + 1] ascending row offsets of the
 // LP instances, first 0, last n_dst; null = one segment).
-std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst);
+std::vector<int> host_stream_tiles(const int64_t* seg_ptr, int64_t n_seg, int64_t n_dst, int geom = 0);
 
+// geom: stream_layout.h::STREAM_GEOM_* (0 = the plain SpMM's).  The walk treats the first 16 floats of a staged item
+// as the feature row (H is read with a stride of ITEM / 4 floats).
 // 0 on success, an MLLP_E* code with *err set otherwise (sizes beyond int32 steps).  max_threads = 0: hardware
 // concurrency, at most 16.
 int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t n_dst, int64_t n_src,
-                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads = 0);
+                      const int64_t* seg_ptr, int64_t n_seg, HostStream* out, std::string* err, unsigned max_threads = 0, int geom = 0);
 
 // Y[n_dst,16] (double) += the product, computed by walking the copy the way spmm_stream_kernel does (records, passes,
 // steps, groups); returns the number of real (non-padding) entries visited, -1 on a malformed copy.
-int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y);
+int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y, int geom = 0);
 
 }  // namespace mllp

@@ -59,6 +59,9 @@ struct StreamCopy {
 
 struct Orient {
     StreamCopy stream;  // plain SpMM on the streamed copy (stream_spmm.hip); takes precedence over `tiled`
+    StreamCopy stream_attn;  // geometry 1: attention forward (stream_attn.hip); takes precedence over tiled_attn
+    StreamCopy stream_bdst;  // geometry 3: destination-major attention backward; over tiled_bdst
+    StreamCopy stream_bsrc;  // geometry 2: source-major attention backward (this orientation = its rows); over tiled_bsrc
     Tiled tiled;        // variant 0: geometry of the plain SpMM
     Tiled tiled_attn;   // variant 1: geometry of the attention forward sweep
     Tiled tiled_bdst;   // variant 4: geometry of the destination-major attention backward sweep
@@ -191,11 +194,19 @@ ConvWs conv_ws_carve(float* base, int64_t n_dst, int cin);
 
 // ---- launchers (sweep_kernels.hip / node_kernels.hip) -------------------------------------------
 int launch_spmm(const Orient& o, const float* H, float* Y, float* scratch, hipStream_t s);
-int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s);   // stream_build.hip
+int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s,
+                        int geom = 0);   // stream_build.hip (geom: stream_layout.h::STREAM_GEOM_*)
 void stream_copy_free(StreamCopy& sc);                                                  // stream_api.cpp
 int build_tiled_device(const Orient& o, int64_t nnz, int variant, Tiled& out, hipStream_t s);   // tiled_build.hip
 void tiled_free(Tiled& tl);                                                             // tiled_build.hip (owned arrays only)
 int launch_spmm_stream(const StreamCopy& sc, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
+struct ConvWs;
+int launch_fwd16_stream(const StreamCopy& sc, int n_dst, int n_src, const float* conv_params, const ConvWs& w,
+                        const float* x_src, const float* x_dst, float* h_out, hipStream_t s);      // stream_attn.hip
+int launch_bwddst16_stream(const StreamCopy& sc, int n_dst, int n_src, const ConvWs& w, const float* x_src, const float* g,
+                           float* dx_dst, int accumulate, hipStream_t s);
+int launch_bwdsrc16_stream(const StreamCopy& sc, int n_rows, int n_cols, const float* rec, const float* x_rows, float* dx,
+                           int accumulate, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);
 int launch_spmm_tiled_bf16(const Tiled& tl, int n_dst, int n_src, const void* H_bf16, float* Y, hipStream_t s);
 struct ConvWs;

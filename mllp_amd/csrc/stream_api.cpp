@@ -19,7 +19,7 @@ void stream_copy_free(StreamCopy& sc) {
     sc = StreamCopy();
 }
 
-static int build_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t>& seg, StreamCopy& sc, hipStream_t s) {
+static int build_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t>& seg, StreamCopy& sc, hipStream_t s, int geom) {
     std::vector<int> ptr((size_t)o.n_dst + 1, 0), idx((size_t)std::max<int64_t>(nnz, 1));
     std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
     MLLP_HIP_TRY(hipStreamSynchronize(s));
@@ -30,7 +30,7 @@ static int build_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t
     }
     HostStream h;
     std::string err;
-    const int rc = host_build_stream(ptr.data(), idx.data(), val.data(), o.n_dst, o.n_src, seg.data(), (int64_t)seg.size() - 1, &h, &err);
+    const int rc = host_build_stream(ptr.data(), idx.data(), val.data(), o.n_dst, o.n_src, seg.data(), (int64_t)seg.size() - 1, &h, &err, 0, geom);
     if (rc) return fail(rc, err);
     sc.n_tiles = h.n_tiles;
     sc.n_tb = h.n_tb;
@@ -55,67 +55,114 @@ using namespace mllp;
 #define REQUIRE(cond, msg) \
     if (!(cond)) return fail(MLLP_EINVAL, std::string(__func__) + ": " + (msg))
 
-extern "C" int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* stream) {
+namespace {
+struct GeomInfo { int R, CB, NW, K0, RQ, ITEM; };
+bool geom_info(int geom, GeomInfo* gi) {
+    switch (geom) {
+        case STREAM_GEOM_SPMM: *gi = {SpmmGeom::R, SpmmGeom::CB, SpmmGeom::NW, SpmmGeom::K0, SpmmGeom::RQ, SpmmGeom::ITEM}; return true;
+        case STREAM_GEOM_ATTN: *gi = {AttnGeom::R, AttnGeom::CB, AttnGeom::NW, AttnGeom::K0, AttnGeom::RQ, AttnGeom::ITEM}; return true;
+        case STREAM_GEOM_BSRC: *gi = {BsrcGeom::R, BsrcGeom::CB, BsrcGeom::NW, BsrcGeom::K0, BsrcGeom::RQ, BsrcGeom::ITEM}; return true;
+        case STREAM_GEOM_BDST: *gi = {BdstGeom::R, BdstGeom::CB, BdstGeom::NW, BdstGeom::K0, BdstGeom::RQ, BdstGeom::ITEM}; return true;
+        default: return false;
+    }
+}
+StreamCopy* copy_slot(mllp_graph_t* g, int transpose, int geom) {
+    Orient& o = transpose ? g->At : g->A;
+    return geom == STREAM_GEOM_SPMM ? &o.stream : geom == STREAM_GEOM_ATTN ? &o.stream_attn : geom == STREAM_GEOM_BSRC ? &o.stream_bsrc :
+           geom == STREAM_GEOM_BDST ? &o.stream_bdst : nullptr;
+}
+}  // namespace
+
+extern "C" int mllp_graph_build_stream_copy(mllp_graph_t* g, int transpose, int geom, int where, void* stream) {
     REQUIRE(g, "null graph");
     REQUIRE(where == 0 || where == 1, "where must be 0 (device builder) or 1 (host reference builder)");
+    GeomInfo gi;
+    REQUIRE(geom_info(geom, &gi), "geom must be 0 (plain SpMM), 1 (attention forward), 2 (source-major backward) or 3 (destination-major backward)");
     Orient& o = transpose ? g->At : g->A;
-    stream_copy_free(o.stream);
+    StreamCopy& slot = *copy_slot(g, transpose, geom);
+    stream_copy_free(slot);
     if (o.n_dst == 0) return MLLP_OK;
     const auto t0 = std::chrono::steady_clock::now();
     StreamCopy sc;
     const std::vector<int64_t>& seg = transpose ? g->h_inst_ptr_n : g->h_inst_ptr_m;     // tiles stay inside an instance
-    const int rc = where == 1 ? build_on_host(o, g->nnz, seg, sc, (hipStream_t)stream)
-                              : build_stream_device(o, g->nnz, host_stream_tiles(seg.data(), (int64_t)seg.size() - 1, o.n_dst),
-                                                    sc, (hipStream_t)stream);
+    const int rc = where == 1 ? build_on_host(o, g->nnz, seg, sc, (hipStream_t)stream, geom)
+                              : build_stream_device(o, g->nnz, host_stream_tiles(seg.data(), (int64_t)seg.size() - 1, o.n_dst, geom),
+                                                    sc, (hipStream_t)stream, geom);
     if (rc) {
         stream_copy_free(sc);
         return rc;
     }
     sc.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    o.stream = sc;
+    slot = sc;
     return MLLP_OK;
 }
 
-extern "C" int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose) {
+extern "C" int mllp_graph_drop_stream_copy(mllp_graph_t* g, int transpose, int geom) {
     REQUIRE(g, "null graph");
-    stream_copy_free((transpose ? g->At : g->A).stream);
+    StreamCopy* sc = copy_slot(g, transpose, geom);
+    REQUIRE(sc, "unknown geometry");
+    stream_copy_free(*sc);
     return MLLP_OK;
 }
 
-extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]) {
+extern "C" int mllp_graph_stream_copy_info(const mllp_graph_t* g, int transpose, int geom, int64_t info[8]) {
     REQUIRE(g && info, "null argument");
-    const StreamCopy& sc = (transpose ? g->At : g->A).stream;
+    GeomInfo gi;
+    REQUIRE(geom_info(geom, &gi), "unknown geometry");
+    const StreamCopy& sc = *copy_slot(const_cast<mllp_graph_t*>(g), transpose, geom);
     info[0] = sc.n_tiles;
     info[1] = sc.n_tb;
     info[2] = sc.n_groups;
     info[3] = sc.step_slots;
-    info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 8 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * S_NW * (256 + 16) +
-                               (sc.n_groups + S_K0) * 64 * S_ENT * 4
+    info[4] = sc.n_tiles ? ((int64_t)sc.n_tiles + 1) * 8 + (int64_t)sc.n_tb * 4 + (int64_t)sc.n_tb * gi.NW * (256 + 16) +
+                               (sc.n_groups + gi.K0) * 64 * 3 * 4
                          : 0;                                   // bytes of the copy
     info[5] = (int64_t)(sc.build_seconds * 1e6);                // microseconds the build took (host clock, synchronised)
-    info[6] = S_R;
-    info[7] = S_CB | S_NW << 16;
+    info[6] = gi.R | (int64_t)gi.RQ << 16 | (int64_t)gi.ITEM << 24;
+    info[7] = gi.CB | gi.NW << 16 | (int64_t)gi.K0 << 24;
     return MLLP_OK;
 }
 
-extern "C" int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which, void* host_dst,
-                                           int64_t capacity_bytes) {
+extern "C" int mllp_graph_export_stream_copy(const mllp_graph_t* g, int transpose, int geom, int which, void* host_dst,
+                                             int64_t capacity_bytes) {
     REQUIRE(g && host_dst, "null argument");
-    const StreamCopy& sc = (transpose ? g->At : g->A).stream;
-    REQUIRE(sc.n_tiles > 0, "no streamed copy of this orientation (mllp_graph_build_spmm_copy)");
+    GeomInfo gi;
+    REQUIRE(geom_info(geom, &gi), "unknown geometry");
+    const StreamCopy& sc = *copy_slot(const_cast<mllp_graph_t*>(g), transpose, geom);
+    REQUIRE(sc.n_tiles > 0, "no streamed copy of this orientation and geometry (mllp_graph_build_stream_copy)");
     const void* src = nullptr;
     int64_t bytes = 0;
     switch (which) {
         case 0: src = sc.tile_blk; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
         case 1: src = sc.blk_id; bytes = (int64_t)sc.n_tb * 4; break;
-        case 2: src = sc.rows; bytes = (int64_t)sc.n_tb * S_NW * 256; break;
-        case 3: src = sc.ent; bytes = (sc.n_groups + S_K0) * 64 * S_ENT * 4; break;
+        case 2: src = sc.rows; bytes = (int64_t)sc.n_tb * gi.NW * 256; break;
+        case 3: src = sc.ent; bytes = (sc.n_groups + gi.K0) * 64 * 3 * 4; break;
         case 4: src = sc.tile_row; bytes = ((int64_t)sc.n_tiles + 1) * 4; break;
-        case 5: src = sc.hdr; bytes = (int64_t)sc.n_tb * S_NW * 16; break;
-        default: return fail(MLLP_EINVAL, "mllp_graph_export_spmm_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rows), 3 (ent), 4 (tile_row) or 5 (hdr)");
+        case 5: src = sc.hdr; bytes = (int64_t)sc.n_tb * gi.NW * 16; break;
+        default: return fail(MLLP_EINVAL, "mllp_graph_export_stream_copy: which must be 0 (tile_blk), 1 (blk_id), 2 (rows), 3 (ent), 4 (tile_row) or 5 (hdr)");
     }
     REQUIRE(capacity_bytes >= bytes, "destination too small");
     MLLP_HIP_TRY(hipDeviceSynchronize());
     if (bytes > 0) MLLP_HIP_TRY(hipMemcpy(host_dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return MLLP_OK;
+}
+
+// the round-3 entry points: geometry 0
+extern "C" int mllp_graph_build_spmm_copy(mllp_graph_t* g, int transpose, int where, void* stream) {
+    return mllp_graph_build_stream_copy(g, transpose, STREAM_GEOM_SPMM, where, stream);
+}
+extern "C" int mllp_graph_drop_spmm_copy(mllp_graph_t* g, int transpose) {
+    return mllp_graph_drop_stream_copy(g, transpose, STREAM_GEOM_SPMM);
+}
+extern "C" int mllp_graph_spmm_copy_info(const mllp_graph_t* g, int transpose, int64_t info[8]) {
+    const int rc = mllp_graph_stream_copy_info(g, transpose, STREAM_GEOM_SPMM, info);
+    if (rc == MLLP_OK) {      // (the round-3 meaning of the last two words)
+        info[6] = S_R;
+        info[7] = S_CB | S_NW << 16;
+    }
+    return rc;
+}
+extern "C" int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which, void* host_dst,
+                                           int64_t capacity_bytes) {
+    return mllp_graph_export_stream_copy(g, transpose, STREAM_GEOM_SPMM, which, host_dst, capacity_bytes);
 }

@@ -26,9 +26,9 @@ void stream_copy_free(StreamCopy& sc);
 
 namespace {
 
-constexpr int SB_T = S_R;       // threads = rows of a tile
 
-__global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ ptr, const int* __restrict__ idx,
+template <class G>
+__global__ __launch_bounds__(G::R) void sb_tile_range(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                       const int* __restrict__ tile_row, int* __restrict__ lo,
                                                       int* __restrict__ hi) {
     __shared__ int s_lo, s_hi;
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ pt
     if (r < tile_row[blockIdx.x + 1]) {
         const int b = ptr[r], e = ptr[r + 1];
         if (e > b) {
-            atomicMin(&s_lo, idx[b] / S_CB);
-            atomicMax(&s_hi, idx[e - 1] / S_CB);
+            atomicMin(&s_lo, idx[b] / G::CB);
+            atomicMax(&s_hi, idx[e - 1] / G::CB);
         }
     }
     __syncthreads();
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(SB_T) void sb_tile_range(const int* __restrict__ pt
 }
 
 // bm: bitmap words of every tile, tile t at bm_off[t] (ceil((hi - lo + 1) / 32) words)
-__global__ __launch_bounds__(SB_T) void sb_tile_bitmap(const int* __restrict__ ptr, const int* __restrict__ idx,
+template <class G>
+__global__ __launch_bounds__(G::R) void sb_tile_bitmap(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                        const int* __restrict__ tile_row, const int* __restrict__ lo, const int* __restrict__ hi,
                                                        const int* __restrict__ bm_off, unsigned* __restrict__ bm,
                                                        int* __restrict__ nb) {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(SB_T) void sb_tile_bitmap(const int* __restrict__ p
         if (threadIdx.x == 0) nb[t] = 0;
         return;
     }
+    constexpr int SB_T = G::R, S_CB = G::CB;
     const int words = (h - l + 32) >> 5;
     for (int i = threadIdx.x; i < words; i += SB_T) s_bm[i] = 0u;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -114,11 +116,13 @@ __global__ __launch_bounds__(64) void sb_tile_blocks(const int* __restrict__ lo,
     }
 }
 
-__global__ __launch_bounds__(SB_T) void sb_count_rows(const int* __restrict__ ptr, const int* __restrict__ idx,
+template <class G>
+__global__ __launch_bounds__(G::R) void sb_count_rows(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                       const int* __restrict__ tile_row, const int* __restrict__ lo, const int* __restrict__ bm_off,
                                                       const unsigned* __restrict__ bm, const int* __restrict__ bm_pref,
                                                       const int* __restrict__ tile_blk, int* __restrict__ cnt,
                                                       int* __restrict__ start) {
+    constexpr int S_R = G::R, S_CB = G::CB;
     const int t = blockIdx.x, r = tile_row[t] + threadIdx.x;
     if (r >= tile_row[t + 1]) return;
     const int l = lo[t], off = bm_off[t], tb0 = tile_blk[t];
@@ -141,8 +145,10 @@ __global__ __launch_bounds__(SB_T) void sb_count_rows(const int* __restrict__ pt
 }
 
 // order[tb][k] = row with the k-th most entries (ties by row); npass[tb][w][2] = {n0 | n1 << 16, n2 | n3 << 16}
-__global__ __launch_bounds__(SB_T) void sb_sort_rows(const int* __restrict__ cnt, int* __restrict__ order,
+template <class G>
+__global__ __launch_bounds__(G::R) void sb_sort_rows(const int* __restrict__ cnt, int* __restrict__ order,
                                                      int* __restrict__ npass) {
+    constexpr int S_R = G::R, S_NW = G::NW, S_P = G::P, S_BR = G::BR;
     __shared__ int c[S_R], ord[S_R];
     const size_t tb = blockIdx.x;
     const int r = threadIdx.x;
@@ -159,14 +165,16 @@ __global__ __launch_bounds__(SB_T) void sb_sort_rows(const int* __restrict__ cnt
     __syncthreads();
     if (r < S_NW) {
         int n[2] = {0, 0};
-        for (int j = 0; j < S_P; ++j) n[j] = c[ord[S_BR * s_bundle(r, j)]];
+        for (int j = 0; j < S_P; ++j) n[j] = c[ord[S_BR * G::bundle(r, j)]];
         npass[(tb * S_NW + r) * 2] = n[0] | n[1] << 16;
         npass[(tb * S_NW + r) * 2 + 1] = 0;
     }
 }
 
+template <class G>
 __global__ void sb_wave_totals(const int* __restrict__ tile_blk, const int* __restrict__ npass, int n_tiles,
                                int* __restrict__ groups) {
+    constexpr int S_NW = G::NW, S_GS = G::GS;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * S_NW) return;
     const int t = i / S_NW, w = i % S_NW;
@@ -178,8 +186,10 @@ __global__ void sb_wave_totals(const int* __restrict__ tile_blk, const int* __re
     groups[i] = (int)((steps + S_GS - 1) / S_GS);
 }
 
+template <class G>
 __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __restrict__ npass, int n_tiles,
                                const int* __restrict__ base_group, int* __restrict__ step_start) {
+    constexpr int S_NW = G::NW, S_GS = G::GS;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * S_NW) return;
     const int t = i / S_NW, w = i % S_NW;
@@ -192,21 +202,30 @@ __global__ void sb_step_starts(const int* __restrict__ tile_blk, const int* __re
 }
 
 // n = number of (group, lane) items of S_ENT ints
+template <class G>
 __global__ void sb_fill_padding(int* __restrict__ ent, long long n) {
+    constexpr int S_ENT = G::ENT, S_PAD_WORD = G::PAD_WORD;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n * S_ENT; i += (long long)gridDim.x * blockDim.x)
         ent[i] = (i % S_ENT) == 0 ? S_PAD_WORD : 0;
 }
 
 // thread = (wavefront w, pass j, row slot, team): the joint ordering of host_stream.cpp::fill_slot for its four rows;
 // the first S_NW x 16 threads also write the row records, the first S_NW the headers
-constexpr int SB_FILL_T = S_NW * S_P * S_RQ * 4;
-static_assert(SB_FILL_T >= S_NW * 16 && SB_FILL_T <= 1024, "sb_fill threads");
-__global__ __launch_bounds__(SB_FILL_T) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
+template <class G>
+struct SbFill {
+    // one thread per (wavefront, pass, row slot, team); at least NW x 16 threads for the row records
+    static constexpr int TEAM_T = G::NW * G::P * G::RQ * 4;
+    static constexpr int T = TEAM_T >= G::NW * 16 ? TEAM_T : G::NW * 16;
+    static_assert(T <= 1024, "sb_fill threads");
+};
+template <class G>
+__global__ __launch_bounds__(SbFill<G>::T) void sb_fill(const int* __restrict__ idx, const float* __restrict__ val,
                                                      const int* __restrict__ blk_id, const int* __restrict__ cnt,
                                                      const int* __restrict__ start, const int* __restrict__ order,
                                                      const int* __restrict__ npass, const int* __restrict__ step_start,
                                                      int4* __restrict__ rows_out, int4* __restrict__ hdr_out,
                                                      int* __restrict__ ent) {
+    constexpr int S_R = G::R, S_NW = G::NW, S_P = G::P, S_RQ = G::RQ, S_BR = G::BR, S_CB = G::CB, S_ROW_BYTES = G::ITEM;
     const size_t tb = blockIdx.x;
     const int tid = threadIdx.x;
     const int* ord = order + tb * S_R;
@@ -214,12 +233,13 @@ __global__ __launch_bounds__(SB_FILL_T) void sb_fill(const int* __restrict__ idx
         const int w = tid >> 4, q = tid & 15;
         int r4[4] = {0, 0, 0, 0};
         for (int j = 0; j < S_P; ++j)
-            for (int r = 0; r < S_RQ; ++r) r4[2 * j + (r >> 1)] |= ord[S_BR * s_bundle(w, j) + 16 * r + q] << (16 * (r & 1));
+            for (int r = 0; r < S_RQ; ++r) r4[2 * j + (r >> 1)] |= ord[S_BR * G::bundle(w, j) + 16 * r + q] << (16 * (r & 1));
         rows_out[(tb * S_NW + w) * 16 + q] = make_int4(r4[0], r4[1], r4[2], r4[3]);
     }
     if (tid < S_NW) hdr_out[tb * S_NW + tid] = make_int4(step_start[tb * S_NW + tid], npass[(tb * S_NW + tid) * 2], blk_id[tb], 0);
+    if (tid >= SbFill<G>::TEAM_T) return;
     const int w = tid / (S_P * S_RQ * 4), pass = (tid / (S_RQ * 4)) % S_P, slot = (tid >> 2) % S_RQ, tm = tid & 3;
-    const int bundle = s_bundle(w, pass);
+    const int bundle = G::bundle(w, pass);
     const unsigned np0 = (unsigned)npass[(tb * S_NW + w) * 2];
     const long long S = (long long)step_start[tb * S_NW + w] + (pass ? (int)(np0 & 0xffffu) : 0);
     const int blk = blk_id[tb];
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(SB_FILL_T) void sb_fill(const int* __restrict__ idx
                 const long long step = S + p;
                 // (the two halves of the offset word may belong to different passes / blocks, i.e. to different
                 // threads: two-byte stores, no read-modify-write)
-                int* dst = ent + s_ent_index(step, quad[i], slot);
+                int* dst = ent + G::ent_index(step, quad[i], slot);
                 reinterpret_cast<unsigned short*>(dst)[step & 1] = (unsigned short)((idx[beg[i] + e] - c0) * S_ROW_BYTES);
                 dst[1 + (step & 1)] = __float_as_int(val[beg[i] + e]);
             }
@@ -288,7 +308,9 @@ struct DevBuf {
 
 }  // namespace
 
-int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s) {
+template <class G>
+static int build_stream_device_t(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s) {
+    constexpr int SB_T = G::R, S_R = G::R, S_NW = G::NW, S_GS = G::GS, S_K0 = G::K0, S_ENT = G::ENT;
     (void)nnz;
     const int n_tiles = (int)tile_row.size() - 1;
     MLLP_HIP_TRY(hipMalloc((void**)&sc.tile_row, ((size_t)n_tiles + 1) * 4));
@@ -297,7 +319,7 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     DevBuf<unsigned> bm;
     if (lo.alloc(n_tiles) || hi.alloc(n_tiles) || bm_off.alloc(n_tiles) || nb.alloc(n_tiles))
         return fail(MLLP_ENOMEM, "streamed copy: hipMalloc failed");
-    hipLaunchKernelGGL(sb_tile_range, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, hi.p);
+    hipLaunchKernelGGL(sb_tile_range<G>, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, hi.p);
     std::vector<int> h_lo(n_tiles), h_hi(n_tiles), h_off(n_tiles), h_nb(n_tiles);
     MLLP_HIP_TRY(hipMemcpyAsync(h_lo.data(), lo.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
     MLLP_HIP_TRY(hipMemcpyAsync(h_hi.data(), hi.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
@@ -317,9 +339,9 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
         return fail(MLLP_ENOMEM, "streamed copy: hipMalloc failed");
     MLLP_HIP_TRY(hipMemcpyAsync(bm_off.p, h_off.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
     if (words_max * 4 > 48 * 1024)
-        MLLP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sb_tile_bitmap),
+        MLLP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sb_tile_bitmap<G>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, words_max * 4));
-    hipLaunchKernelGGL(sb_tile_bitmap, dim3(n_tiles), dim3(SB_T), (size_t)words_max * 4, s, o.ptr, o.idx, sc.tile_row,
+    hipLaunchKernelGGL(sb_tile_bitmap<G>, dim3(n_tiles), dim3(SB_T), (size_t)words_max * 4, s, o.ptr, o.idx, sc.tile_row,
                        lo.p, hi.p, bm_off.p, bm.p, nb.p);
     MLLP_HIP_TRY(hipMemcpyAsync(h_nb.data(), nb.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, s));
     MLLP_HIP_TRY(hipStreamSynchronize(s));
@@ -346,11 +368,11 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     MLLP_HIP_TRY(hipMemsetAsync(start.p, 0, std::max<size_t>(n_slots, 1) * 4, s));
     hipLaunchKernelGGL(sb_tile_blocks, dim3(n_tiles), dim3(64), 0, s, lo.p, hi.p, bm_off.p, bm.p, sc.tile_blk, sc.blk_id,
                        bm_pref.p);
-    hipLaunchKernelGGL(sb_count_rows, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, bm_off.p, bm.p,
+    hipLaunchKernelGGL(sb_count_rows<G>, dim3(n_tiles), dim3(SB_T), 0, s, o.ptr, o.idx, sc.tile_row, lo.p, bm_off.p, bm.p,
                        bm_pref.p, sc.tile_blk, cnt.p, start.p);
-    if (n_tb > 0) hipLaunchKernelGGL(sb_sort_rows, dim3((unsigned)n_tb), dim3(SB_T), 0, s, cnt.p, order.p, npass.p);
+    if (n_tb > 0) hipLaunchKernelGGL(sb_sort_rows<G>, dim3((unsigned)n_tb), dim3(SB_T), 0, s, cnt.p, order.p, npass.p);
     const int nw = n_tiles * S_NW;
-    hipLaunchKernelGGL(sb_wave_totals, dim3((nw + 255) / 256), dim3(256), 0, s, sc.tile_blk, npass.p, n_tiles, groups.p);
+    hipLaunchKernelGGL(sb_wave_totals<G>, dim3((nw + 255) / 256), dim3(256), 0, s, sc.tile_blk, npass.p, n_tiles, groups.p);
     std::vector<int> h_groups(nw), h_base(nw);
     MLLP_HIP_TRY(hipMemcpyAsync(h_groups.data(), groups.p, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
     MLLP_HIP_TRY(hipStreamSynchronize(s));
@@ -362,19 +384,29 @@ int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& ti
     }
     sc.n_groups = n_groups;
     MLLP_HIP_TRY(hipMemcpyAsync(base.p, h_base.data(), (size_t)nw * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sb_step_starts, dim3((nw + 255) / 256), dim3(256), 0, s, sc.tile_blk, npass.p, n_tiles, base.p,
+    hipLaunchKernelGGL(sb_step_starts<G>, dim3((nw + 255) / 256), dim3(256), 0, s, sc.tile_blk, npass.p, n_tiles, base.p,
                        sstart.p);
     const long long n_ent = (long long)(n_groups + S_K0) * 64;
     MLLP_HIP_TRY(hipMalloc((void**)&sc.ent, (size_t)n_ent * S_ENT * 4));
-    hipLaunchKernelGGL(sb_fill_padding, dim3(4096), dim3(256), 0, s, sc.ent, n_ent);
+    hipLaunchKernelGGL(sb_fill_padding<G>, dim3(4096), dim3(256), 0, s, sc.ent, n_ent);
     if (n_tb > 0)
-        hipLaunchKernelGGL(sb_fill, dim3((unsigned)n_tb), dim3(SB_FILL_T), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
+        hipLaunchKernelGGL(sb_fill<G>, dim3((unsigned)n_tb), dim3(SbFill<G>::T), 0, s, o.idx, o.val, sc.blk_id, cnt.p, start.p,
                            order.p, npass.p, sstart.p, reinterpret_cast<int4*>(sc.rows), reinterpret_cast<int4*>(sc.hdr),
                            sc.ent);
     MLLP_HIP_TRY(hipGetLastError());
     sc.step_slots = n_groups * 128;      // entry slots of the stream, padding included
     MLLP_HIP_TRY(hipStreamSynchronize(s));
     return MLLP_OK;
+}
+
+int build_stream_device(const Orient& o, int64_t nnz, const std::vector<int>& tile_row, StreamCopy& sc, hipStream_t s, int geom) {
+    switch (geom) {
+        case STREAM_GEOM_SPMM: return build_stream_device_t<SpmmGeom>(o, nnz, tile_row, sc, s);
+        case STREAM_GEOM_ATTN: return build_stream_device_t<AttnGeom>(o, nnz, tile_row, sc, s);
+        case STREAM_GEOM_BSRC: return build_stream_device_t<BsrcGeom>(o, nnz, tile_row, sc, s);
+        case STREAM_GEOM_BDST: return build_stream_device_t<BdstGeom>(o, nnz, tile_row, sc, s);
+        default: return fail(MLLP_EINVAL, "streamed copy: unknown geometry");
+    }
 }
 
 }  // namespace mllp

@@ -703,6 +703,8 @@ int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const Co
     a.X = x_src; a.xd = x_dst; a.qp = w.qp; a.t = w.t; a.derived = w.derived;
     a.p = conv_params_at(conv_params, cin);
     a.h = h_out; a.Z = w.Z; a.aux = w.aux;
+    if (cin == 16 && o.stream_attn.n_tiles > 0)
+        return launch_fwd16_stream(o.stream_attn, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     if (cin == 16 && o.tiled_attn.n_tiles > 0)
         return launch_fwd16_tiled(o.tiled_attn, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     if (cin == 16) return launch_sweep<Fwd16Op, 4, 4>(o, a, scratch, s, "attn_fwd16");
@@ -717,6 +719,8 @@ int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, cons
     BwdDstArgs a;
     a.X = x_src; a.rec = w.rec; a.g = g; a.derived = w.derived;
     a.dqp = w.dqp; a.dsdt = w.dsdt; a.dx_dst = dx_dst; a.accumulate = accumulate;
+    if (cin == 16 && o.stream_bdst.n_tiles > 0)
+        return launch_bwddst16_stream(o.stream_bdst, o.n_dst, o.n_src, w, x_src, g, dx_dst, accumulate, s);
     if (cin == 16 && o.tiled_bdst.n_tiles > 0)
         return launch_bwddst16_tiled(o.tiled_bdst, o.n_dst, o.n_src, w, x_src, g, dx_dst, accumulate, s);
     if (cin == 16) return launch_sweep<BwdDst16Op, 4, 4>(o, a, scratch, s, "attn_bwd_dst16");
@@ -727,6 +731,9 @@ int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, cons
 
 int launch_attn_bwd_src(const Orient& o_src_major, const ConvWs& w, const float* x_src, float* dx_src, int accumulate,
                         float* scratch, hipStream_t s) {
+    if (o_src_major.stream_bsrc.n_tiles > 0)
+        return launch_bwdsrc16_stream(o_src_major.stream_bsrc, o_src_major.n_dst, o_src_major.n_src, w.rec, x_src, dx_src,
+                                      accumulate, s);
     if (o_src_major.tiled_bsrc.n_tiles > 0)
         return launch_bwdsrc16_tiled(o_src_major.tiled_bsrc, o_src_major.n_dst, o_src_major.n_src, w.rec, x_src, dx_src,
                                      accumulate, s);

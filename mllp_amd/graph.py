@@ -7,6 +7,7 @@ CSR(A) + CSR(A^T) behind an opaque `mllp_graph_t*`, and every model call takes i
 """
 import ctypes
 import itertools
+import time
 from ctypes import c_int32, c_int64, c_double, c_void_p
 from typing import List, Optional, Sequence
 
@@ -394,6 +395,57 @@ class LPBatch:
                                                               a.ctypes.data_as(c_void_p), a.nbytes))
             out.append(a)
         return tuple(out)
+
+    # ---- streamed copies of the attention sweeps (round 4; stream_attn.hip) ----------------------------
+    GEOM_SPMM, GEOM_ATTN, GEOM_BSRC, GEOM_BDST = 0, 1, 2, 3
+
+    def build_stream_copy(self, transpose=False, geom=1, where="device"):
+        """Build the streamed copy of geometry `geom` (0 plain SpMM, 1 attention forward, 2 source-major backward,
+        3 destination-major backward) of A (or A^T); the sweeps use it when present.  Returns `stream_copy_info`."""
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().mllp_graph_build_stream_copy(self._h, int(transpose), int(geom),
+                                                           {"device": 0, "host": 1}[where], _lib.current_stream()))
+        self.stream_build_s = getattr(self, "stream_build_s", 0.0) + time.perf_counter() - t0
+        return self.stream_copy_info(transpose, geom)
+
+    def drop_stream_copy(self, transpose=False, geom=1):
+        _lib.check(_lib.lib().mllp_graph_drop_stream_copy(self._h, int(transpose), int(geom)))
+
+    def stream_copy_info(self, transpose=False, geom=1):
+        d = (c_int64 * 8)()
+        _lib.check(_lib.lib().mllp_graph_stream_copy_info(self._h, int(transpose), int(geom), d))
+        keys = ["n_tiles", "n_tb", "n_groups", "entry_slots", "bytes", "build_us"]
+        out = dict(zip(keys, [int(v) for v in d[:6]]))
+        out.update(row_slots=int(d[6]) & 0xffff, rows_per_quad=(int(d[6]) >> 16) & 0xff, item_bytes=int(d[6]) >> 24,
+                   cols_per_block=int(d[7]) & 0xffff, wavefronts=(int(d[7]) >> 16) & 0xff, pad_groups=int(d[7]) >> 24)
+        return out
+
+    def export_stream_copy(self, transpose=False, geom=1):
+        """(tile_blk, blk_id, rows [n_tb, nw, 16, 4], ent [groups + padding, 64, 3], tile_row, hdr [n_tb, nw, 4]) as numpy
+        int32 arrays (tests)."""
+        i = self.stream_copy_info(transpose, geom)
+        nw = i["wavefronts"]
+        shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], nw, 16, 4), (i["n_groups"] + i["pad_groups"], 64, 3),
+                  (i["n_tiles"] + 1,), (i["n_tb"], nw, 4)]
+        out = []
+        for which, shp in enumerate(shapes):
+            a = np.empty(shp, dtype=np.int32)
+            _lib.check(_lib.lib().mllp_graph_export_stream_copy(self._h, int(transpose), int(geom), which,
+                                                                a.ctypes.data_as(c_void_p), a.nbytes))
+            out.append(a)
+        return tuple(out)
+
+    def enable_stream_step(self):
+        """The streamed copies that the TRAINING STEP's 16-channel attention sweeps use, both orientations: forward (1),
+        source-major backward (2), destination-major backward (3).  Returns {(transpose, geom): info}."""
+        return {(tr, g): self.build_stream_copy(tr, g) for tr in (False, True) for g in self.STREAM_STEP_GEOMS}
+
+    def disable_stream_step(self):
+        for tr in (False, True):
+            for g in self.STREAM_STEP_GEOMS:
+                self.drop_stream_copy(tr, g)
+
+    STREAM_STEP_GEOMS = (1, 2, 3)
 
     def enable_tiled_all(self):
         """Attach every LDS-tiled copy (variants 0-4, both orientations): the throughput configuration for batches of

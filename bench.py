@@ -343,50 +343,85 @@ def main():
              "GBps": b_at / ms_gat / 1e6, "frac": b_at / ms_gat / 1e6 / HBM_PEAK_GBS},
         ]
         del Ym, Yn, ref_a, ref_at
+        # the full-size parity figures are gates, not prints: a regression ends the run non-zero
+        gate_fail = []
+        if os.environ.get("MLLP_BENCH_PERTURB"):      # (tests: a deliberately perturbed comparison must end the run non-zero)
+            err_a += float(os.environ["MLLP_BENCH_PERTURB"])
+        for name_, err_, lim_ in (("spmm_stream A*H", err_a, 2e-6), ("spmm_stream At*H", err_at, 2e-6)):
+            if not err_ <= lim_:
+                gate_fail.append(f"{name_}: max_rel_diff_vs_generic {err_:.3e} > {lim_:.0e}")
         sb.tiled_build_s = 0.0                       # from here on: the copies of the training step
         lg_generic = sb.loss_step(params0, 1.0 / sb.n_inst)[1].clone()      # whole model on the generic sweeps, full size
-        # one attention conv forward (16-wide), destination = constraints: generic sweep, then the LDS-tiled one
-        cp = params0[1392:1392 + 1104].contiguous()
-        ws = sb.tconv_workspace(False, 16)
-        h = [None]
+        # One 16-channel attention conv, forward and backward (all its kernels, as the step runs them), in BOTH orientations
+        # (dst = constraints walks A, dst = variables walks A^T: twice the rows, half the row length): generic sweeps, LDS-tiled
+        # sweeps (rounds 2-3), streamed sweeps (round 4, stream_attn.hip).  Bytes: forward = pattern + source rows once + per
+        # destination node_qp (x read, q' and t written) and the sweep (q', t, x read; h, Z, aux written) = 408 B; backward =
+        # two pattern sweeps + node tensors.
+        conv_diffs = {}
+        for dst_is_var, off_, label in ((False, 1392, "dst=constraints"), (True, 288, "dst=variables")):
+            nd_, ns_ = (sb.N, sb.M) if dst_is_var else (sb.M, sb.N)
+            x_s, x_d = (Hm, Hn) if dst_is_var else (Hn, Hm)
+            cp = params0[off_:off_ + 1104].contiguous()
+            ws = sb.tconv_workspace(dst_is_var, 16)
+            dh = torch.randn(nd_, 16, device="cuda")
+            h = [None]
 
-        def conv_f():
-            h[0] = sb.tconv_fwd(False, 16, cp, Hn, Hm, ws)
-        # forward bytes: pattern + source rows once + per destination: node_qp (x read, q' and t written) and the
-        # sweep (q', t, x read; h, Z, aux written) = 132 + 132 + 144 = 408 B
-        b_f = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 64 + sb.M * 408
-        ms_fg = timed(conv_f, 10, warm=3)
-        kernels.append({"kernel": "tconv_fwd16 generic (prep + node_qp + attention sweep from L2), dst=constraints",
-                        "ms": ms_fg, "alg_bytes": b_f, "GBps": b_f / ms_fg / 1e6, "frac": b_f / ms_fg / 1e6 / HBM_PEAK_GBS})
-        if sb.enable_tiled(False, variant=1) and sb.enable_tiled(True, variant=1):
-            ms_ft = timed(conv_f, 10, warm=3)
-            kernels.append({"kernel": "tconv_fwd16 LDS-tiled (prep + node_qp + fwd16_tiled_kernel), dst=constraints",
-                            "ms": ms_ft, "alg_bytes": b_f, "GBps": b_f / ms_ft / 1e6,
-                            "frac": b_f / ms_ft / 1e6 / HBM_PEAK_GBS})
-        # one attention conv backward (bwd_pre + destination-major sweep + source-major sweep + parameter statistics):
-        # generic gathers, then with the LDS-tiled source-major sweep (variant 2 copy on the orientation whose rows are
-        # the conv's sources).  Bytes: two pattern sweeps + node tensors
-        dh = torch.randn(sb.M, 16, device="cuda")
-        b_b = 16 * sb.nnz + 192 * sb.N + 1216 * sb.M
+            def conv_f():
+                h[0] = sb.tconv_fwd(dst_is_var, 16, cp, x_s, x_d, ws)
 
-        def conv_b():
-            sb.tconv_bwd(False, 16, cp, Hn, Hm, h[0], ws, dh)
-        conv_f()
-        ms_bg = timed(conv_b, 6, warm=2)
-        kernels.append({"kernel": "tconv_bwd16 generic (bwd_pre + dst sweep + src gather sweep + stats), dst=constraints",
-                        "ms": ms_bg, "alg_bytes": b_b, "GBps": b_b / ms_bg / 1e6, "frac": b_b / ms_bg / 1e6 / HBM_PEAK_GBS})
-        if sb.enable_tiled(True, variant=2) and sb.enable_tiled(False, variant=2):
-            ms_bt = timed(conv_b, 6, warm=2)
-            kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel, dst=constraints",
-                            "ms": ms_bt, "alg_bytes": b_b, "GBps": b_b / ms_bt / 1e6,
-                            "frac": b_b / ms_bt / 1e6 / HBM_PEAK_GBS})
-        # ... and with the lane-per-row destination-major sweep as well (variant 4 copy on the conv's own orientation)
-        if sb.enable_tiled(False, variant=4) and sb.enable_tiled(True, variant=4):
-            ms_bd = timed(conv_b, 6, warm=2)
-            kernels.append({"kernel": "tconv_bwd16 with bwdsrc16_tiled_kernel and bwddst16_lane_kernel, dst=constraints",
-                            "ms": ms_bd, "alg_bytes": b_b, "GBps": b_b / ms_bd / 1e6,
-                            "frac": b_b / ms_bd / 1e6 / HBM_PEAK_GBS})
-        del ws, h, Hm, dh
+            def conv_b():
+                return sb.tconv_bwd(dst_is_var, 16, cp, x_s, x_d, h_ref, ws, dh.clone())
+            b_f = sb.nnz * 8 + 4 * (nd_ + 1) + ns_ * 64 + nd_ * 408
+            b_b = 16 * sb.nnz + 192 * ns_ + 1216 * nd_
+
+            def line(kind, what, ms_, by_):
+                return {"kernel": f"{kind} {what}, {label}", "ms": ms_, "alg_bytes": by_, "GBps": by_ / ms_ / 1e6,
+                        "frac": by_ / ms_ / 1e6 / HBM_PEAK_GBS}
+            ms_fg = timed(conv_f, 6, warm=2)
+            h_ref = h[0].clone()                      # (every backward below masks with THIS forward's ReLU pattern)
+            ms_bg = timed(conv_b, 4, warm=1)
+            ref_b = [t_.clone() for t_ in conv_b()[:3]]
+            kernels.append(line("tconv_fwd16", "generic (prep + node_qp + attention sweep from L2)", ms_fg, b_f))
+            kernels.append(line("tconv_bwd16", "generic (bwd_pre + dst sweep + src gather sweep + stats)", ms_bg, b_b))
+            for kind in ("LDS-tiled", "streamed"):
+                if kind == "LDS-tiled":
+                    ok = (sb.enable_tiled(dst_is_var, variant=1) and sb.enable_tiled(not dst_is_var, variant=2)
+                          and sb.enable_tiled(dst_is_var, variant=4))
+                    names = ("fwd16_tiled_kernel", "bwdsrc16_tiled_kernel + bwddst16_lane_kernel")
+                else:
+                    infos_ = {g_: sb.build_stream_copy(dst_is_var if g_ != 2 else not dst_is_var, g_) for g_ in (1, 2, 3)}
+                    ok = all(i_["n_tiles"] > 0 for i_ in infos_.values())
+                    names = ("fwd16_stream_kernel", "bwdsrc16_stream_kernel + bwddst16_stream_kernel")
+                if not ok:
+                    continue
+                ms_f = timed(conv_f, 10, warm=3)
+                d_h = float((h[0] - h_ref).abs().max() / h_ref.abs().max())
+                ms_b = timed(conv_b, 6, warm=2)
+                got_b = conv_b()[:3]
+                d_b = [float((g_ - r_).abs().max() / r_.abs().max()) for g_, r_ in zip(got_b, ref_b)]
+                lf = line("tconv_fwd16", f"{kind} (prep + node_qp + {names[0]})", ms_f, b_f)
+                lb = line("tconv_bwd16", f"{kind} (bwd_pre + {names[1]} + stats)", ms_b, b_b)
+                lf["max_rel_diff_vs_generic"] = d_h
+                lb["max_rel_diff_vs_generic"] = {"param_grads": d_b[0], "dx_dst": d_b[1], "dx_src": d_b[2]}
+                if kind == "streamed":
+                    lf["copy_build_s"] = infos_[1]["build_us"] / 1e6
+                    lb["copy_build_s"] = (infos_[2]["build_us"] + infos_[3]["build_us"]) / 1e6
+                    lf["entry_slots_per_nnz"] = infos_[1]["entry_slots"] / sb.nnz
+                    conv_diffs[label] = (d_h, max(d_b))
+                    if not d_h <= 2e-6:
+                        gate_fail.append(f"tconv_fwd16 streamed {label}: {d_h:.3e} > 2e-6")
+                    if not max(d_b) <= 5e-6:
+                        gate_fail.append(f"tconv_bwd16 streamed {label}: {max(d_b):.3e} > 5e-6")
+                kernels.append(lf)
+                kernels.append(lb)
+                if kind == "LDS-tiled":       # (the streamed copies take precedence anyway; drop these: 34 GB at 256 instances)
+                    sb.disable_tiled(dst_is_var, variant=1); sb.disable_tiled(not dst_is_var, variant=2)
+                    sb.disable_tiled(dst_is_var, variant=4)
+                else:
+                    for g_ in (1, 2, 3):
+                        sb.drop_stream_copy(dst_is_var if g_ != 2 else not dst_is_var, g_)
+            del ws, dh, h_ref, ref_b
+        del Hm
         # layer-1 (one channel) conv: generic sweeps, then the LDS-tiled lane-per-row kernels (variant 3)
         cp1 = params0[144:288].contiguous()
         x1s, x1d = torch.randn(sb.N, device="cuda"), torch.randn(sb.M, device="cuda")
@@ -395,7 +430,7 @@ def main():
         ms_1g = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
         kernels.append({"kernel": "tconv_fwd1 generic (lane per nonzero, 4-byte gathers from L2), dst=constraints",
                         "ms": ms_1g, "alg_bytes": b_f1, "GBps": b_f1 / ms_1g / 1e6, "frac": b_f1 / ms_1g / 1e6 / HBM_PEAK_GBS})
-        if sb.enable_tiled(False, variant=3) and sb.enable_tiled(True, variant=3):
+        if sb.enable_tiled(False, variant=3):
             ms_1t = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
             kernels.append({"kernel": "tconv_fwd1 LDS-tiled (scalar_tiled_kernel, lane per row), dst=constraints",
                             "ms": ms_1t, "alg_bytes": b_f1, "GBps": b_f1 / ms_1t / 1e6,
@@ -413,12 +448,18 @@ def main():
                                              "corrected; precomputed, not measured by this run)",
                            "kernels": kernels}
         del Hn
-        # full training step on the synthetic batch with every tiled copy of the attention sweeps attached; its logits
-        # against those of the generic sweeps at the same full size (taken above, before any copy was attached)
+        # full training step on the synthetic batch with the copies LPTrainer attaches by itself (streamed copies of the
+        # 16-channel sweeps, LDS-tiled variant 3 for layer 1); its logits against those of the generic sweeps at the same full
+        # size (taken above, before any copy was attached)
+        sb.disable_tiled(False, variant=3)
+        sb.tiled_build_s = 0.0
+        sb.stream_build_s = 0.0
         tr = LPTrainer(params0, lr=1e-3, use_hip_graph=False, global_instances=sb.n_inst * world)
-        tr._plan(sb)                                   # (the tiled copies of the attention sweeps were attached above)
+        tr._plan(sb)
         lg_tiled = sb.loss_step(params0, 1.0 / sb.n_inst)[1]
         logits_diff = float((lg_tiled - lg_generic).abs().max() / lg_generic.abs().max())
+        if not logits_diff <= 5e-6:
+            gate_fail.append(f"training step logits, streamed vs generic: {logits_diff:.3e} > 5e-6")
         del lg_generic, lg_tiled
         for _ in range(2):
             tr.step(sb)
@@ -436,9 +477,15 @@ def main():
                             "graph_build_s": getattr(sb, "graph_build_s", None),
                             "graph_build": "CSR -> CSC (one stable device sort) + row tiers, mllp_graph_create_device",
                             "tiled_build_s": getattr(sb, "tiled_build_s", None),
-                            "tiled_build": "8 LDS-tiled copies of the attention sweeps (variants 1-4 x 2 orientations), HIP builder "
-                                           "(mllp_graph_build_tiled; round 2's torch builder took 68 s)",
-                            "logits_max_rel_diff_tiled_vs_generic": logits_diff}
+                            "stream_build_s": getattr(sb, "stream_build_s", None),
+                            "copies": "6 streamed copies of the 16-channel attention sweeps (geometries 1-3 x 2 orientations, "
+                                      "mllp_graph_build_stream_copy) + 2 LDS-tiled copies of the layer-1 sweeps (variant 3, "
+                                      "mllp_graph_build_tiled), HIP builders",
+                            "logits_max_rel_diff_streamed_vs_generic": logits_diff,
+                            "logits_max_rel_diff_tiled_vs_generic": logits_diff,
+                            "parity_gates": {"failed": list(gate_fail), "limits": "SpMM / conv forward 2e-6, conv backward and "
+                                             "step logits 5e-6 (max-norm relative, streamed vs generic sweeps, full size)"}}
+        out["parity_gate_failures"] = list(gate_fail)
         # configs[4] as STRONG scaling: one Adam step per 2048 instances = 8 / N micro-batches of 256 per rank, gradients
         # accumulated, one all-reduce.  The micro-batches reuse the resident synthetic batch (same work per launch;
         # 8 distinct 256-instance batches with their tiled copies do not fit in 288 GB).
@@ -485,6 +532,9 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if out.get("parity_gate_failures"):
+        print("bench.py: parity gate(s) failed: " + "; ".join(out["parity_gate_failures"]), file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -122,8 +122,9 @@ struct AttnArgs {
 #define AK_OWN2 AK_QP(2, 2, 3, 3)     // ... in lanes 2, 3
 #define AK_OTH0 AK_QP(1, 1, 0, 0)
 #define AK_OTH2 AK_QP(3, 3, 2, 2)
-#define AK_OFF_EVEN(OFFR) "v_and_b32 " OFFR ", 0xffff, %[o]\n\t"
-#define AK_OFF_ODD(OFFR) "v_lshrrev_b32 " OFFR ", 16, %[o]\n\t"
+// offset of an even / odd step out of the lane's offset word W (an asm operand name)
+#define AK_OFF_EVEN(OFFR, W) "v_and_b32 " OFFR ", 0xffff, %[" W "]\n\t"
+#define AK_OFF_ODD(OFFR, W) "v_lshrrev_b32 " OFFR ", 16, %[" W "]\n\t"
 #define AK_PKMUL(D, A, B) "v_pk_mul_f32 " D ", " A ", " B "\n\t"
 #define AK_PKFMA(D, A, B) "v_pk_fma_f32 " D ", " A ", " B ", " D "\n\t"
 #define AK_PKACC(D, S, X) "v_pk_fma_f32 " D ", " S ", " X ", " D " op_sel_hi:[0,1,1]\n\t"      // D += S.lo * X (both halves)
@@ -131,8 +132,8 @@ struct AttnArgs {
 struct AkConst {      // per-lane / per-wavefront constants and the running flags of a pass
     unsigned pb, pz, pbs;         // LDS address of the lane's piece of item 0 of the image; of the all-zero item; of item 0's scalars
     int ninf;                     // -inf
-    float k;                      // forward: 64 (the window of the fast pass); source-major backward: log2(e)
-    unsigned long long viol, real_e, real_o;
+    float k;                      // source-major backward: log2(e)
+    unsigned long long real_e, real_o;
 };
 #define AK_CLOBBER_TOP                                                                                                \
     "memory", "vcc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",   \
@@ -142,54 +143,73 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
 #define AK_CLOBBER_F AK_CLOBBER_TOP
 #define AK_CLOBBER_D AK_CLOBBER_TOP, "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119"
 #define AK_CLOBBER_B AK_CLOBBER_D, "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105"
-#define AK_IO(CLOB) : [viol] "+s"(c.viol), [re] "+s"(c.real_e), [ro] "+s"(c.real_o), [t2] "=&s"(t2) \
-                    : [o] "v"(o), [val] "v"(val), [pb] "v"(c.pb), [pz] "v"(c.pz), [pbs] "v"(c.pbs), [k] "s"(c.k), [ninf] "v"(c.ninf) : CLOB
 #define AK_REAL(REALR, ADR) "v_cmp_ne_u32_e64 " REALR ", " ADR ", %[pz]\n\t"
+// Ablations (variant libraries of the timing build only, `make -C mllp_amd/csrc abl ABL=n`; the results are wrong): bit 0 = no
+// LDS reads in the sites, bit 1 = no arithmetic in the sites, bit 2 = no staging, bit 3 = no state load / store per pass,
+// bit 4 = no reloads of the entry registers, bit 5 = stagers without pacing
+#if defined(MLLP_TIMING_BUILD) && defined(MLLP_AK_ABL)
+constexpr int AK_ABL = MLLP_AK_ABL;
+#else
+constexpr int AK_ABL = 0;
+#endif
+#if defined(MLLP_TIMING_BUILD) && defined(MLLP_AK_ABL) && (MLLP_AK_ABL & 1)
+#define AK_DSREAD(X) ""
+#else
+#define AK_DSREAD(X) X
+#endif
+#if defined(MLLP_TIMING_BUILD) && defined(MLLP_AK_ABL) && (MLLP_AK_ABL & 2)
+#define AK_ARITH(X) ""
+#else
+#define AK_ARITH(X) X
+#endif
 
 // ===== forward =====  fixed registers (compiled for 120 VGPRs):
 //   v[120:123] v[124:127]   item pieces of an EVEN step: slot 0 (the lane's own row), slot 1 (the pair's other row)
 //   v[128:131] v[132:135]   the same of an ODD step
 //   v[136:139] v[140:143]   q' pieces (log2 units): own row, other row          v[144:147] v[148:151]   running Z likewise
 //   v152 L   v153 u   v154 m   v155 t            (the lane's own row)
-//   v156 / v157  the lane's offsets of the even / odd step        v158  LDS address        v159  partial sum -> logit -> l - m
+//   v156  the lane's offsets of the step to read        v158  LDS address        v159  partial sum -> logit -> l - m
 //   v[160:161] v[162:163]   dot-product pairs, then a t - m (v161), the other pair's partial (v162), a (v163)
-//   v[164:165] p (own row) as pk_fma operand      v[166:167] p of the other row
-#define FK_DOT(C0L, C0H, C1L, C1H, READ0)                                                                 \
-    AK_PKMUL("v[160:161]", C0L, "v[136:137]") AK_PKMUL("v[162:163]", C1L, "v[140:141]") READ0            \
+//   v164 p (own row; v[164:165] as pk_fma operand, which reads the low half only)   v165 running max of |l - m| of the pass
+//   v[166:167] p of the other row
+// A site = the arithmetic of step S - 1, then the reads of step S + 1 into the registers that step S - 1 has just left: the
+// reads run TWO steps ahead on two register sets, every step has ONE copy of its code (a first version with separate
+// "both / reads only / arithmetic only" copies and the block body inlined twice was 48-63 KB per kernel: the instruction
+// cache that two CUs share holds 64 KB, and a site took 600 cycles whatever it contained -- profiles/r04_attn_stream_cycles.txt).
+// The pass starts with the reads of its first two steps (AK_PRO) and ends with two reads too many (of whatever follows in
+// the stream: harmless, waited for before the state is stored).
+#define FK_READS(OFFR, XR0, XR1, OWNR, OTHR, REALR)                                                       \
+    "v_add_u32_dpp v158, " OFFR ", %[pb]" OWNR AK_DSREAD("ds_read_b128 " XR0 ", v158\n\t") AK_REAL(REALR, "v158")     \
+    "v_add_u32_dpp v158, " OFFR ", %[pb]" OTHR AK_DSREAD("ds_read_b128 " XR1 ", v158\n\t")
+#define FK_DOT(C0L, C0H, C1L, C1H)                                                                        \
+    AK_PKMUL("v[160:161]", C0L, "v[136:137]") AK_PKMUL("v[162:163]", C1L, "v[140:141]")                  \
     AK_PKFMA("v[160:161]", C0H, "v[138:139]") AK_PKFMA("v[162:163]", C1H, "v[142:143]")
-// partial sums; a of the own row; a t - m; += the other pair's partial of the own row
-#define FK_RED_A(OWNC)                                                    \
-    "v_add_f32 v159, v160, v161\n\t"                                      \
+// partial sums of the own / the other row; a of the own row; both summed over the lane pair; a t - m; (OFFN); + the other
+// pair's sum of the own row; l - m; padding -> -inf; p = 2^(l - m); running max of |l - m| (also the wait state of the
+// exponential); L, u; the other row's p; Z
+#define FK_RED(OWNC, OFFN, REALC)                                         \
+    AK_ARITH("v_add_f32 v159, v160, v161\n\t"                             \
     "v_add_f32 v162, v162, v163\n\t"                                      \
     "v_mov_b32_dpp v163, %[val]" OWNC                                     \
-    "v_fma_f32 v161, v163, v155, -v154\n\t"                               \
-    "v_add_f32_dpp v159, v162, v159" AK_QP(2, 3, 0, 1)
-// (two instructions here -- "is the entry just read a real one?" and the address of the second read, or s_nop 1 -- are the
-// two wait states in front of the DPP read of v159)  the pair's sum; l - m; |l - m| > 64 ?; padding -> -inf; p = 2^(l - m).
-// The result of the exponential needs one wait state: the second read is issued behind it.
-#define FK_RED_B(REALC)                                                   \
     "v_add_f32_dpp v159, v159, v159" AK_QP(1, 0, 3, 2)                    \
+    "v_add_f32_dpp v162, v162, v162" AK_QP(1, 0, 3, 2)                    \
+    "v_fma_f32 v161, v163, v155, -v154\n\t") OFFN                         \
+    AK_ARITH("v_add_f32_dpp v159, v162, v159" AK_QP(2, 3, 0, 1)           \
     "v_add_f32 v159, v159, v161\n\t"                                      \
-    "v_cmp_gt_f32_e64 %[t2], |v159|, %[k]\n\t"                            \
-    "s_or_b64 %[viol], %[viol], %[t2]\n\t"                                \
-    "v_cndmask_b32_e64 v159, %[ninf], v159, " REALC "\n\t"                \
-    "v_exp_f32_e32 v164, v159\n\t"
+    "v_cndmask_b32_e64 v164, %[ninf], v159, " REALC "\n\t"                \
+    "v_exp_f32_e32 v164, v164\n\t"                                        \
+    "v_max_f32_e64 v165, v165, |v159|\n\t")
 #define FK_ACC(C0L, C0H, C1L, C1H)                                        \
     "v_add_f32 v152, v152, v164\n\t"                                      \
     "v_fmac_f32 v153, v164, v163\n\t"                                     \
     "v_mov_b32_dpp v166, v164" AK_QP(2, 3, 0, 1)                          \
     AK_PKACC("v[144:145]", "v[164:165]", C0L) AK_PKACC("v[146:147]", "v[164:165]", C0H) \
     AK_PKACC("v[148:149]", "v[166:167]", C1L) AK_PKACC("v[150:151]", "v[166:167]", C1H)
-#define FK_READ0(OFFR, XR0, OWNR) "v_add_u32_dpp v158, " OFFR ", %[pb]" OWNR "ds_read_b128 " XR0 ", v158\n\t"
-#define FK_ADDR1(OFFR, OTHR) "v_add_u32_dpp v158, " OFFR ", %[pb]" OTHR
-#define FK_READ1(XR1) "ds_read_b128 " XR1 ", v158\n\t"
-#define FK_BOTH(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC)                  \
-    "s_waitcnt lgkmcnt(0)\n\t" OFFX(OFFR) FK_DOT(C0L, C0H, C1L, C1H, FK_READ0(OFFR, XR0, OWNR))             \
-        FK_RED_A(OWNC) AK_REAL(REALR, "v158") FK_ADDR1(OFFR, OTHR) FK_RED_B(REALC) FK_READ1(XR1) FK_ACC(C0L, C0H, C1L, C1H)
-#define FK_RDONLY(OFFX, OFFR, XR0, XR1, OWNR, OTHR, REALR) \
-    OFFX(OFFR) "s_nop 1\n\t" FK_READ0(OFFR, XR0, OWNR) AK_REAL(REALR, "v158") FK_ADDR1(OFFR, OTHR) FK_READ1(XR1)
-#define FK_CMONLY(C0L, C0H, C1L, C1H, OWNC, REALC) \
-    "s_waitcnt lgkmcnt(0)\n\t" FK_DOT(C0L, C0H, C1L, C1H, "") FK_RED_A(OWNC) "s_nop 1\n\t" FK_RED_B(REALC) "s_nop 0\n\t" FK_ACC(C0L, C0H, C1L, C1H)
+#define FK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)                          \
+    "s_waitcnt lgkmcnt(2)\n\t" AK_ARITH(FK_DOT(C0L, C0H, C1L, C1H)) FK_RED(OWNC, OFFN, REALC)              \
+        AK_ARITH(FK_ACC(C0L, C0H, C1L, C1H)) FK_READS("v156", XR0, XR1, OWNR, OTHR, REALR)
+#define FK_PRO(OFFA, XA0, XA1, OWNA, OTHA, REALA, OFFB, XB0, XB1, OWNB, OTHB, REALB)                       \
+    OFFA "s_nop 1\n\t" FK_READS("v156", XA0, XA1, OWNA, OTHA, REALA) OFFB "s_nop 1\n\t" FK_READS("v156", XB0, XB1, OWNB, OTHB, REALB)
 #define FK_E "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]"
 #define FK_O "v[128:129]", "v[130:131]", "v[132:133]", "v[134:135]"
 
@@ -198,33 +218,35 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
 //   v[108:111] v[112:115]   item pieces of an EVEN step (own row, other row)       v[116:119] v[120:123]   of an ODD step
 //   v[124:127] v[128:131] q' (log2 units)   v[132:135] v[136:139] gv   v[140:143] v[144:147] running dq'    (own, other)
 //   v148 t   v149 m   v150 1/L   v151 ge   v152 c   v153 dt       (the lane's own row)
-//   v154 / v155 offsets of the even / odd step       v164 LDS address
+//   v154 offsets of the step to read       v164 LDS address
 //   v[156:157] l-dot own -> l - m -> 2^(l - m) -> dl     v[158:159] l-dot other     v[160:161] dalpha-dot own -> e     v[162:163] other
 //   v[166:167] dl of the other row
-#define DK_DOT(C0L, C0H, C1L, C1H, READ0)                                                                   \
-    AK_PKMUL("v[156:157]", C0L, "v[124:125]") AK_PKMUL("v[158:159]", C1L, "v[128:129]") READ0              \
+#define DK_READS(OFFR, XR0, XR1, OWNR, OTHR, REALR)                                                       \
+    "v_add_u32_dpp v164, " OFFR ", %[pb]" OWNR AK_DSREAD("ds_read_b128 " XR0 ", v164\n\t") AK_REAL(REALR, "v164")     \
+    "v_add_u32_dpp v164, " OFFR ", %[pb]" OTHR AK_DSREAD("ds_read_b128 " XR1 ", v164\n\t")
+#define DK_DOT(C0L, C0H, C1L, C1H)                                                                          \
+    AK_PKMUL("v[156:157]", C0L, "v[124:125]") AK_PKMUL("v[158:159]", C1L, "v[128:129]")                    \
     AK_PKMUL("v[160:161]", C0L, "v[132:133]") AK_PKMUL("v[162:163]", C1L, "v[136:137]")                    \
     AK_PKFMA("v[156:157]", C0H, "v[126:127]") AK_PKFMA("v[158:159]", C1H, "v[130:131]")                    \
     AK_PKFMA("v[160:161]", C0H, "v[134:135]") AK_PKFMA("v[162:163]", C1H, "v[138:139]")
-#define DK_RED_A(OWNC)                                                    \
+// partial sums; a; += the other pair's partials of the own row; a t - m; a ge + c; (OFFN); sums over the pair; l - m;
+// e = dalpha + c; padding -> -inf; 2^(l - m); e / L (also the wait state of the exponential); dl
+#define DK_RED(OWNC, OFFN, REALC)                                         \
     "v_add_f32 v156, v156, v157\n\t"                                      \
     "v_add_f32 v158, v158, v159\n\t"                                      \
     "v_add_f32 v160, v160, v161\n\t"                                      \
     "v_add_f32 v162, v162, v163\n\t"                                      \
     "v_mov_b32_dpp v106, %[val]" OWNC                                     \
     "v_add_f32_dpp v156, v158, v156" AK_QP(2, 3, 0, 1)                    \
-    "v_add_f32_dpp v160, v162, v160" AK_QP(2, 3, 0, 1)
-// (two instructions here: the wait states of the DPP reads)  sums over the pair; a t - m; a ge + c; l - m; e = dalpha + c;
-// padding -> -inf; 2^(l - m); e / L (also the wait state of the exponential); dl
-#define DK_RED_B(REALC, READ1)                                            \
+    "v_add_f32_dpp v160, v162, v160" AK_QP(2, 3, 0, 1)                    \
+    "v_fma_f32 v107, v106, v148, -v149\n\t"                               \
+    "v_fma_f32 v157, v106, v151, v152\n\t" OFFN                           \
     "v_add_f32_dpp v156, v156, v156" AK_QP(1, 0, 3, 2)                    \
     "v_add_f32_dpp v160, v160, v160" AK_QP(1, 0, 3, 2)                    \
-    "v_fma_f32 v107, v106, v148, -v149\n\t"                               \
-    "v_fma_f32 v157, v106, v151, v152\n\t"                                \
     "v_add_f32 v156, v156, v107\n\t"                                      \
     "v_add_f32 v160, v160, v157\n\t"                                      \
     "v_cndmask_b32_e64 v156, %[ninf], v156, " REALC "\n\t"                \
-    "v_exp_f32_e32 v156, v156\n\t" READ1                                  \
+    "v_exp_f32_e32 v156, v156\n\t"                                        \
     "v_mul_f32 v160, v160, v150\n\t"                                      \
     "v_mul_f32 v156, v156, v160\n\t"
 #define DK_ACC(C0L, C0H, C1L, C1H)                                        \
@@ -233,16 +255,11 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
     "v_mov_b32_dpp v166, v156" AK_QP(2, 3, 0, 1)                          \
     AK_PKACC("v[142:143]", "v[156:157]", C0H)                             \
     AK_PKACC("v[144:145]", "v[166:167]", C1L) AK_PKACC("v[146:147]", "v[166:167]", C1H)
-#define DK_READ0(OFFR, XR0, OWNR) "v_add_u32_dpp v164, " OFFR ", %[pb]" OWNR "ds_read_b128 " XR0 ", v164\n\t"
-#define DK_ADDR1(OFFR, OTHR) "v_add_u32_dpp v164, " OFFR ", %[pb]" OTHR
-#define DK_READ1(XR1) "ds_read_b128 " XR1 ", v164\n\t"
-#define DK_BOTH(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC)                  \
-    "s_waitcnt lgkmcnt(0)\n\t" OFFX(OFFR) DK_DOT(C0L, C0H, C1L, C1H, DK_READ0(OFFR, XR0, OWNR))             \
-        DK_RED_A(OWNC) AK_REAL(REALR, "v164") DK_ADDR1(OFFR, OTHR) DK_RED_B(REALC, DK_READ1(XR1)) DK_ACC(C0L, C0H, C1L, C1H)
-#define DK_RDONLY(OFFX, OFFR, XR0, XR1, OWNR, OTHR, REALR) \
-    OFFX(OFFR) "s_nop 1\n\t" DK_READ0(OFFR, XR0, OWNR) AK_REAL(REALR, "v164") DK_ADDR1(OFFR, OTHR) DK_READ1(XR1)
-#define DK_CMONLY(C0L, C0H, C1L, C1H, OWNC, REALC) \
-    "s_waitcnt lgkmcnt(0)\n\t" DK_DOT(C0L, C0H, C1L, C1H, "") DK_RED_A(OWNC) "s_nop 1\n\t" DK_RED_B(REALC, "") DK_ACC(C0L, C0H, C1L, C1H)
+#define DK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)                          \
+    "s_waitcnt lgkmcnt(2)\n\t" DK_DOT(C0L, C0H, C1L, C1H) DK_RED(OWNC, OFFN, REALC) DK_ACC(C0L, C0H, C1L, C1H) \
+        DK_READS("v154", XR0, XR1, OWNR, OTHR, REALR)
+#define DK_PRO(OFFA, XA0, XA1, OWNA, OTHA, REALA, OFFB, XB0, XB1, OWNB, OTHB, REALB)                       \
+    OFFA "s_nop 1\n\t" DK_READS("v154", XA0, XA1, OWNA, OTHA, REALA) OFFB "s_nop 1\n\t" DK_READS("v154", XB0, XB1, OWNB, OTHB, REALB)
 #define DK_E "v[108:109]", "v[110:111]", "v[112:113]", "v[114:115]"
 #define DK_O "v[116:117]", "v[118:119]", "v[120:121]", "v[122:123]"
 
@@ -253,31 +270,30 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
 //   ODD step:  v[118:121]       v[122:125]         v[126:129]           v[130:133]           v[134:137]                      v138
 //   v[140:143] v[144:147] x_j (own row, other row)      v[148:151] v[152:155] running dx_j
 //   v[156:157] l-dot own -> l - rowmax -> 2^.. -> dl    v[158:159] l-dot other -> alpha    v[160:161] dalpha-dot own -> e -> dl of the other row
-//   v[162:163] dalpha-dot other -> alpha of the other row        v164 / v165 offsets of the even / odd step
-#define BK_DOT(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, READ0)                                              \
-    AK_PKMUL("v[156:157]", Q0L, "v[140:141]") AK_PKMUL("v[158:159]", Q1L, "v[144:145]") READ0              \
+//   v[162:163] dalpha-dot other -> alpha of the other row        v164 offsets of the step to read
+#define BK_DOT(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H)                                                     \
+    AK_PKMUL("v[156:157]", Q0L, "v[140:141]") AK_PKMUL("v[158:159]", Q1L, "v[144:145]")                    \
     AK_PKMUL("v[160:161]", G0L, "v[140:141]") AK_PKMUL("v[162:163]", G1L, "v[144:145]")                    \
     AK_PKFMA("v[156:157]", Q0H, "v[142:143]") AK_PKFMA("v[158:159]", Q1H, "v[146:147]")                    \
     AK_PKFMA("v[160:161]", G0H, "v[142:143]") AK_PKFMA("v[162:163]", G1H, "v[146:147]")
-#define BK_RED_A(OWNC)                                                    \
+// T, RM, RI, GE, CC: the scalars of the own row's record of the computed step
+#define BK_RED(OWNC, OFFN, REALC, T, RM, RI, GE, CC)                      \
     "v_add_f32 v156, v156, v157\n\t"                                      \
     "v_add_f32 v158, v158, v159\n\t"                                      \
     "v_add_f32 v160, v160, v161\n\t"                                      \
     "v_add_f32 v162, v162, v163\n\t"                                      \
     "v_mov_b32_dpp v94, %[val]" OWNC                                      \
     "v_add_f32_dpp v156, v158, v156" AK_QP(2, 3, 0, 1)                    \
-    "v_add_f32_dpp v160, v162, v160" AK_QP(2, 3, 0, 1)
-// T, RM, RI, GE, CC: the scalars of the own row's record of the computed step
-#define BK_RED_B(REALC, READ1, T, RM, RI, GE, CC)                         \
+    "v_add_f32_dpp v160, v162, v160" AK_QP(2, 3, 0, 1)                    \
+    "v_fma_f32 v95, v94, " T ", -" RM "\n\t"                              \
+    "v_fma_f32 v157, v94, " GE ", " CC "\n\t" OFFN                        \
     "v_add_f32_dpp v156, v156, v156" AK_QP(1, 0, 3, 2)                    \
     "v_add_f32_dpp v160, v160, v160" AK_QP(1, 0, 3, 2)                    \
-    "v_fma_f32 v95, v94, " T ", -" RM "\n\t"                              \
-    "v_fma_f32 v157, v94, " GE ", " CC "\n\t"                             \
     "v_add_f32 v156, v156, v95\n\t"                                       \
-    "v_add_f32 v160, v160, v157\n\t"                                      \
     "v_mul_f32 v156, %[k], v156\n\t"                                      \
     "v_cndmask_b32_e64 v156, %[ninf], v156, " REALC "\n\t"                \
-    "v_exp_f32_e32 v156, v156\n\t" READ1                                  \
+    "v_exp_f32_e32 v156, v156\n\t"                                        \
+    "v_add_f32 v160, v160, v157\n\t"                                      \
     "v_mul_f32 v158, v156, " RI "\n\t"                                    \
     "v_mul_f32 v156, v158, v160\n\t"
 #define BK_ACC(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H)                    \
@@ -289,11 +305,11 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
     AK_PKACC("v[152:153]", "v[162:163]", G1L) AK_PKACC("v[154:155]", "v[162:163]", G1H)                    \
     AK_PKACC("v[152:153]", "v[160:161]", Q1L) AK_PKACC("v[154:155]", "v[160:161]", Q1H)
 // (the scalars of a record sit at its byte 128 for every lane: their address leaves out the lane's piece offset)
-#define BK_READ0(OFFR, RQ0, RG0, RSC, RC, OWNR)                                                          \
-    "v_add_u32_dpp v117, " OFFR ", %[pb]" OWNR "ds_read_b128 " RQ0 ", v117\n\tds_read_b128 " RG0 ", v117 offset:64\n\t" \
-    "v_add_u32_dpp v95, " OFFR ", %[pbs]" OWNR "ds_read_b128 " RSC ", v95\n\tds_read_b32 " RC ", v95 offset:16\n\t"
-#define BK_ADDR1(OFFR, OTHR) "v_add_u32_dpp v117, " OFFR ", %[pb]" OTHR
-#define BK_READ1(RQ1, RG1) "ds_read_b128 " RQ1 ", v117\n\tds_read_b128 " RG1 ", v117 offset:64\n\t"
+#define BK_READS(OFFR, RQ0, RG0, RSC, RC, RQ1, RG1, OWNR, OTHR, REALR)                                   \
+    "v_add_u32_dpp v117, " OFFR ", %[pb]" OWNR AK_DSREAD("ds_read_b128 " RQ0 ", v117\n\tds_read_b128 " RG0 ", v117 offset:64\n\t") \
+    "v_add_u32_dpp v95, " OFFR ", %[pbs]" OWNR AK_DSREAD("ds_read_b128 " RSC ", v95\n\tds_read_b32 " RC ", v95 offset:16\n\t")     \
+    AK_REAL(REALR, "v117")                                                                                \
+    "v_add_u32_dpp v117, " OFFR ", %[pb]" OTHR AK_DSREAD("ds_read_b128 " RQ1 ", v117\n\tds_read_b128 " RG1 ", v117 offset:64\n\t")
 // register names of a step's items: E = even, O = odd
 #define BK_RE "v[96:99]", "v[100:103]", "v[112:115]", "v116"
 #define BK_RE1 "v[104:107]", "v[108:111]"
@@ -304,67 +320,87 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
 #define BK_SE "v112", "v113", "v114", "v115", "v116"
 #define BK_SO "v134", "v135", "v136", "v137", "v138"
 // (the packs above are passed by name and expand one level down)
-#define BK_BOTH(OFFX, OFFR, R, R1, C, S, OWNR, OTHR, OWNC, REALR, REALC) BK_BOTH_X(OFFX, OFFR, R, R1, C, S, OWNR, OTHR, OWNC, REALR, REALC)
-#define BK_BOTH_X(OFFX, OFFR, RQ0, RG0, RSC, RC, RQ1, RG1, Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, T, RM, RI, GE, CC, OWNR, OTHR, OWNC, REALR, REALC) \
-    "s_waitcnt lgkmcnt(0)\n\t" OFFX(OFFR) BK_DOT(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, BK_READ0(OFFR, RQ0, RG0, RSC, RC, OWNR))                     \
-        BK_RED_A(OWNC) AK_REAL(REALR, "v117") BK_ADDR1(OFFR, OTHR) BK_RED_B(REALC, BK_READ1(RQ1, RG1), T, RM, RI, GE, CC)                              \
-        BK_ACC(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H)
-#define BK_RDONLY(OFFX, OFFR, R, R1, OWNR, OTHR, REALR) BK_RDONLY_X(OFFX, OFFR, R, R1, OWNR, OTHR, REALR)
-#define BK_RDONLY_X(OFFX, OFFR, RQ0, RG0, RSC, RC, RQ1, RG1, OWNR, OTHR, REALR) \
-    OFFX(OFFR) "s_nop 1\n\t" BK_READ0(OFFR, RQ0, RG0, RSC, RC, OWNR) AK_REAL(REALR, "v117") BK_ADDR1(OFFR, OTHR) BK_READ1(RQ1, RG1)
-#define BK_CMONLY(C, S, OWNC, REALC) BK_CMONLY_X(C, S, OWNC, REALC)
-#define BK_CMONLY_X(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, T, RM, RI, GE, CC, OWNC, REALC)                                       \
-    "s_waitcnt lgkmcnt(0)\n\t" BK_DOT(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, "") BK_RED_A(OWNC) "s_nop 1\n\t"                   \
-        BK_RED_B(REALC, "s_nop 0\n\t", T, RM, RI, GE, CC) BK_ACC(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H)
+#define BK_SITE(C, S, OWNC, REALC, OFFN, R, R1, OWNR, OTHR, REALR) BK_SITE_X(C, S, OWNC, REALC, OFFN, R, R1, OWNR, OTHR, REALR)
+#define BK_SITE_X(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H, T, RM, RI, GE, CC, OWNC, REALC, OFFN, RQ0, RG0, RSC, RC, RQ1, RG1, OWNR, OTHR, REALR) \
+    "s_waitcnt lgkmcnt(6)\n\t" BK_DOT(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H) BK_RED(OWNC, OFFN, REALC, T, RM, RI, GE, CC)                       \
+        BK_ACC(Q0L, Q0H, G0L, G0H, Q1L, Q1H, G1L, G1H) BK_READS("v164", RQ0, RG0, RSC, RC, RQ1, RG1, OWNR, OTHR, REALR)
+#define BK_PRO(OFFA, RA, RA1, OWNA, OTHA, REALA, OFFB, RB, RB1, OWNB, OTHB, REALB) BK_PRO_X(OFFA, RA, RA1, OWNA, OTHA, REALA, OFFB, RB, RB1, OWNB, OTHB, REALB)
+#define BK_PRO_X(OFFA, AQ0, AG0, ASC, AC, AQ1, AG1, OWNA, OTHA, REALA, OFFB, BQ0, BG0, BSC, BC, BQ1, BG1, OWNB, OTHB, REALB) \
+    OFFA "s_nop 1\n\t" BK_READS("v164", AQ0, AG0, ASC, AC, AQ1, AG1, OWNA, OTHA, REALA)                                    \
+    OFFB "s_nop 1\n\t" BK_READS("v164", BQ0, BG0, BSC, BC, BQ1, BG1, OWNB, OTHB, REALB)
 
 // forwarding macros: the F / D families take their computed pieces as one macro argument (FK_E, ...)
-#define FK_BOTH_(OFFX, OFFR, XR0, XR1, C, OWNR, OTHR, OWNC, REALR, REALC) FK_BOTH_X(OFFX, OFFR, XR0, XR1, C, OWNR, OTHR, OWNC, REALR, REALC)
-#define FK_BOTH_X(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC) FK_BOTH(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC)
-#define FK_CMONLY_(C, OWNC, REALC) FK_CMONLY_X(C, OWNC, REALC)
-#define FK_CMONLY_X(C0L, C0H, C1L, C1H, OWNC, REALC) FK_CMONLY(C0L, C0H, C1L, C1H, OWNC, REALC)
-#define DK_BOTH_(OFFX, OFFR, XR0, XR1, C, OWNR, OTHR, OWNC, REALR, REALC) DK_BOTH_X(OFFX, OFFR, XR0, XR1, C, OWNR, OTHR, OWNC, REALR, REALC)
-#define DK_BOTH_X(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC) DK_BOTH(OFFX, OFFR, XR0, XR1, C0L, C0H, C1L, C1H, OWNR, OTHR, OWNC, REALR, REALC)
-#define DK_CMONLY_(C, OWNC, REALC) DK_CMONLY_X(C, OWNC, REALC)
-#define DK_CMONLY_X(C0L, C0H, C1L, C1H, OWNC, REALC) DK_CMONLY(C0L, C0H, C1L, C1H, OWNC, REALC)
+#define FK_SITE_(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) FK_SITE_X(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
+#define FK_SITE_X(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) FK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
+#define DK_SITE_(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) DK_SITE_X(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
+#define DK_SITE_X(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) DK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
 
-// Site of step S (S counted from the first step of the register set's first group).  `o`: the lane's offset word of the
-// group of step S; `val`: its value of step S - 1.  SM 0 = both, 1 = reads only (first step of a pass), 2 = arithmetic only
-// (behind the last step).
-template <int MODE, int S4, int SM>
-__device__ __forceinline__ void ak_site(int o, int val, AkConst& c) {
-    unsigned long long t2;
-    constexpr int C4 = (S4 + 3) & 3;     // the computed step (S - 1) mod 4
-    constexpr bool EV = (S4 & 1) == 0;   // the step that is READ is even (the computed one is odd)
-#define AK_EMIT(OWNR, OTHR, OWNC)                                                                                          \
+#define AK_IO_(CLOB) : [re] "+s"(c.real_e), [ro] "+s"(c.real_o) \
+                     : [oa] "v"(oa), [ob] "v"(ob), [val] "v"(val), [pb] "v"(c.pb), [pz] "v"(c.pz), [pbs] "v"(c.pbs), [k] "s"(c.k), [ninf] "v"(c.ninf) : CLOB
+// Site S (S counted from the first step of the register set's first group; S4 = S mod 4): arithmetic of step S - 1 (`val`: the
+// lane's value of that step), reads of step S + 1 (`ob`: the lane's offset word of the group of step S + 1).
+template <int MODE, int S4>
+__device__ __forceinline__ void ak_site(int ob, int val, AkConst& c) {
+    const int oa = 0;
+    constexpr bool CEV = (S4 & 1) == 1;            // the computed step S - 1 (and the read step S + 1) is even
+    constexpr bool COWN0 = ((S4 + 3) & 3) < 2;     // the computed step sits in lanes 0, 1 of the quad
+    constexpr bool ROWN0 = ((S4 + 1) & 3) < 2;     // the read step ...
+#define AK_EMIT(OWNC, OWNR, OTHR)                                                                                          \
     if constexpr (MODE == MODE_FWD) {                                                                                      \
-        if constexpr (SM == 0 && EV) asm volatile(FK_BOTH_(AK_OFF_EVEN, "v156", "v[120:123]", "v[124:127]", FK_O, OWNR, OTHR, OWNC, "%[re]", "%[ro]") AK_IO(AK_CLOBBER_F)); \
-        if constexpr (SM == 0 && !EV) asm volatile(FK_BOTH_(AK_OFF_ODD, "v157", "v[128:131]", "v[132:135]", FK_E, OWNR, OTHR, OWNC, "%[ro]", "%[re]") AK_IO(AK_CLOBBER_F)); \
-        if constexpr (SM == 1 && EV) asm volatile(FK_RDONLY(AK_OFF_EVEN, "v156", "v[120:123]", "v[124:127]", OWNR, OTHR, "%[re]") AK_IO(AK_CLOBBER_F)); \
-        if constexpr (SM == 1 && !EV) asm volatile(FK_RDONLY(AK_OFF_ODD, "v157", "v[128:131]", "v[132:135]", OWNR, OTHR, "%[ro]") AK_IO(AK_CLOBBER_F)); \
-        if constexpr (SM == 2 && EV) asm volatile(FK_CMONLY_(FK_O, OWNC, "%[ro]") AK_IO(AK_CLOBBER_F));                    \
-        if constexpr (SM == 2 && !EV) asm volatile(FK_CMONLY_(FK_E, OWNC, "%[re]") AK_IO(AK_CLOBBER_F));                   \
+        if constexpr (CEV) asm volatile(FK_SITE_(FK_E, OWNC, "%[re]", AK_OFF_EVEN("v156", "ob"), "v[120:123]", "v[124:127]", OWNR, OTHR, "%[re]") AK_IO_(AK_CLOBBER_F)); \
+        else asm volatile(FK_SITE_(FK_O, OWNC, "%[ro]", AK_OFF_ODD("v156", "ob"), "v[128:131]", "v[132:135]", OWNR, OTHR, "%[ro]") AK_IO_(AK_CLOBBER_F));               \
     } else if constexpr (MODE == MODE_BDST) {                                                                              \
-        if constexpr (SM == 0 && EV) asm volatile(DK_BOTH_(AK_OFF_EVEN, "v154", "v[108:111]", "v[112:115]", DK_O, OWNR, OTHR, OWNC, "%[re]", "%[ro]") AK_IO(AK_CLOBBER_D)); \
-        if constexpr (SM == 0 && !EV) asm volatile(DK_BOTH_(AK_OFF_ODD, "v155", "v[116:119]", "v[120:123]", DK_E, OWNR, OTHR, OWNC, "%[ro]", "%[re]") AK_IO(AK_CLOBBER_D)); \
-        if constexpr (SM == 1 && EV) asm volatile(DK_RDONLY(AK_OFF_EVEN, "v154", "v[108:111]", "v[112:115]", OWNR, OTHR, "%[re]") AK_IO(AK_CLOBBER_D)); \
-        if constexpr (SM == 1 && !EV) asm volatile(DK_RDONLY(AK_OFF_ODD, "v155", "v[116:119]", "v[120:123]", OWNR, OTHR, "%[ro]") AK_IO(AK_CLOBBER_D)); \
-        if constexpr (SM == 2 && EV) asm volatile(DK_CMONLY_(DK_O, OWNC, "%[ro]") AK_IO(AK_CLOBBER_D));                    \
-        if constexpr (SM == 2 && !EV) asm volatile(DK_CMONLY_(DK_E, OWNC, "%[re]") AK_IO(AK_CLOBBER_D));                   \
+        if constexpr (CEV) asm volatile(DK_SITE_(DK_E, OWNC, "%[re]", AK_OFF_EVEN("v154", "ob"), "v[108:111]", "v[112:115]", OWNR, OTHR, "%[re]") AK_IO_(AK_CLOBBER_D)); \
+        else asm volatile(DK_SITE_(DK_O, OWNC, "%[ro]", AK_OFF_ODD("v154", "ob"), "v[116:119]", "v[120:123]", OWNR, OTHR, "%[ro]") AK_IO_(AK_CLOBBER_D));               \
     } else {                                                                                                               \
-        if constexpr (SM == 0 && EV) asm volatile(BK_BOTH(AK_OFF_EVEN, "v164", BK_RE, BK_RE1, BK_CO, BK_SO, OWNR, OTHR, OWNC, "%[re]", "%[ro]") AK_IO(AK_CLOBBER_B)); \
-        if constexpr (SM == 0 && !EV) asm volatile(BK_BOTH(AK_OFF_ODD, "v165", BK_RO, BK_RO1, BK_CE, BK_SE, OWNR, OTHR, OWNC, "%[ro]", "%[re]") AK_IO(AK_CLOBBER_B)); \
-        if constexpr (SM == 1 && EV) asm volatile(BK_RDONLY(AK_OFF_EVEN, "v164", BK_RE, BK_RE1, OWNR, OTHR, "%[re]") AK_IO(AK_CLOBBER_B)); \
-        if constexpr (SM == 1 && !EV) asm volatile(BK_RDONLY(AK_OFF_ODD, "v165", BK_RO, BK_RO1, OWNR, OTHR, "%[ro]") AK_IO(AK_CLOBBER_B)); \
-        if constexpr (SM == 2 && EV) asm volatile(BK_CMONLY(BK_CO, BK_SO, OWNC, "%[ro]") AK_IO(AK_CLOBBER_B));             \
-        if constexpr (SM == 2 && !EV) asm volatile(BK_CMONLY(BK_CE, BK_SE, OWNC, "%[re]") AK_IO(AK_CLOBBER_B));            \
+        if constexpr (CEV) asm volatile(BK_SITE(BK_CE, BK_SE, OWNC, "%[re]", AK_OFF_EVEN("v164", "ob"), BK_RE, BK_RE1, OWNR, OTHR, "%[re]") AK_IO_(AK_CLOBBER_B)); \
+        else asm volatile(BK_SITE(BK_CO, BK_SO, OWNC, "%[ro]", AK_OFF_ODD("v164", "ob"), BK_RO, BK_RO1, OWNR, OTHR, "%[ro]") AK_IO_(AK_CLOBBER_B));               \
     }
-    // lanes of the read step: 0, 1 when S4 < 2; of the computed step: 0, 1 when C4 < 2
-    if constexpr (S4 < 2 && C4 < 2) { AK_EMIT(AK_OWN0, AK_OTH0, AK_OWN0) }
-    else if constexpr (S4 < 2) { AK_EMIT(AK_OWN0, AK_OTH0, AK_OWN2) }
-    else if constexpr (C4 < 2) { AK_EMIT(AK_OWN2, AK_OTH2, AK_OWN0) }
-    else { AK_EMIT(AK_OWN2, AK_OTH2, AK_OWN2) }
+    if constexpr (COWN0 && ROWN0) { AK_EMIT(AK_OWN0, AK_OWN0, AK_OTH0) }
+    else if constexpr (COWN0) { AK_EMIT(AK_OWN0, AK_OWN2, AK_OTH2) }
+    else if constexpr (ROWN0) { AK_EMIT(AK_OWN2, AK_OWN0, AK_OTH0) }
+    else { AK_EMIT(AK_OWN2, AK_OWN2, AK_OTH2) }
 #undef AK_EMIT
 }
+// Start of a pass at step RA (0 .. 3 inside its group): the reads of steps RA and RA + 1.  `oa`: offset word of the group of
+// step RA, `ob`: of step RA + 1 (the next group's when RA = 3).
+template <int MODE, int RA>
+__device__ __forceinline__ void ak_prologue(int oa, int ob, AkConst& c) {
+    const int val = 0;
+    constexpr bool AEV = (RA & 1) == 0;
+#define AK_PA(M, E0, E1, O0, O1)                                                                                           \
+    if constexpr (RA == 0) asm volatile(M(AK_OFF_EVEN(OFFREG, "oa"), E0, E1, AK_OWN0, AK_OTH0, "%[re]", AK_OFF_ODD(OFFREG, "ob"), O0, O1, AK_OWN0, AK_OTH0, "%[ro]") AK_IO_(CLOB)); \
+    if constexpr (RA == 1) asm volatile(M(AK_OFF_ODD(OFFREG, "oa"), O0, O1, AK_OWN0, AK_OTH0, "%[ro]", AK_OFF_EVEN(OFFREG, "ob"), E0, E1, AK_OWN2, AK_OTH2, "%[re]") AK_IO_(CLOB)); \
+    if constexpr (RA == 2) asm volatile(M(AK_OFF_EVEN(OFFREG, "oa"), E0, E1, AK_OWN2, AK_OTH2, "%[re]", AK_OFF_ODD(OFFREG, "ob"), O0, O1, AK_OWN2, AK_OTH2, "%[ro]") AK_IO_(CLOB)); \
+    if constexpr (RA == 3) asm volatile(M(AK_OFF_ODD(OFFREG, "oa"), O0, O1, AK_OWN2, AK_OTH2, "%[ro]", AK_OFF_EVEN(OFFREG, "ob"), E0, E1, AK_OWN0, AK_OTH0, "%[re]") AK_IO_(CLOB));
+    (void)AEV;
+    if constexpr (MODE == MODE_FWD) {
+#define OFFREG "v156"
+#define CLOB AK_CLOBBER_F
+        AK_PA(FK_PRO, "v[120:123]", "v[124:127]", "v[128:131]", "v[132:135]")
+#undef OFFREG
+#undef CLOB
+    } else if constexpr (MODE == MODE_BDST) {
+#define OFFREG "v154"
+#define CLOB AK_CLOBBER_D
+        AK_PA(DK_PRO, "v[108:111]", "v[112:115]", "v[116:119]", "v[120:123]")
+#undef OFFREG
+#undef CLOB
+    } else {
+#define OFFREG "v164"
+#define CLOB AK_CLOBBER_B
+#define BK_PA_(OA, RA_, RA1_, OWA, OTA, REA, OB, RB_, RB1_, OWB, OTB, REB) BK_PRO(OA, RA_, RA1_, OWA, OTA, REA, OB, RB_, RB1_, OWB, OTB, REB)
+        if constexpr (RA == 0) asm volatile(BK_PRO(AK_OFF_EVEN(OFFREG, "oa"), BK_RE, BK_RE1, AK_OWN0, AK_OTH0, "%[re]", AK_OFF_ODD(OFFREG, "ob"), BK_RO, BK_RO1, AK_OWN0, AK_OTH0, "%[ro]") AK_IO_(CLOB));
+        if constexpr (RA == 1) asm volatile(BK_PRO(AK_OFF_ODD(OFFREG, "oa"), BK_RO, BK_RO1, AK_OWN0, AK_OTH0, "%[ro]", AK_OFF_EVEN(OFFREG, "ob"), BK_RE, BK_RE1, AK_OWN2, AK_OTH2, "%[re]") AK_IO_(CLOB));
+        if constexpr (RA == 2) asm volatile(BK_PRO(AK_OFF_EVEN(OFFREG, "oa"), BK_RE, BK_RE1, AK_OWN2, AK_OTH2, "%[re]", AK_OFF_ODD(OFFREG, "ob"), BK_RO, BK_RO1, AK_OWN2, AK_OTH2, "%[ro]") AK_IO_(CLOB));
+        if constexpr (RA == 3) asm volatile(BK_PRO(AK_OFF_ODD(OFFREG, "oa"), BK_RO, BK_RO1, AK_OWN2, AK_OTH2, "%[ro]", AK_OFF_EVEN(OFFREG, "ob"), BK_RE, BK_RE1, AK_OWN0, AK_OTH0, "%[re]") AK_IO_(CLOB));
+#undef BK_PA_
+#undef OFFREG
+#undef CLOB
+    }
+#undef AK_PA
+}
+#undef AK_IO_
 
 // state of the lane's two rows: LDS -> the fixed registers, and back.  `own` / `oth`: byte offset of the lane's 16-byte piece
 // of its own / the other row inside a [rows][64 B] array; `sc`: byte address of the own row's scalars.
@@ -373,7 +409,7 @@ __device__ __forceinline__ void ak_state_load(unsigned own, unsigned oth, unsign
     using M = AM<MODE>;
     if constexpr (MODE == MODE_FWD)
         asm volatile("ds_read_b128 v[136:139], %0\n\tds_read_b128 v[140:143], %1\n\t"
-                     "ds_read_b128 v[144:147], %2\n\tds_read_b128 v[148:151], %3\n\tds_read_b128 v[152:155], %4"
+                     "ds_read_b128 v[144:147], %2\n\tds_read_b128 v[148:151], %3\n\tds_read_b128 v[152:155], %4\n\tv_mov_b32 v165, 0"
                      : : "v"(own + M::QA), "v"(oth + M::QA), "v"(own + M::ZA), "v"(oth + M::ZA), "v"(sc) : AK_CLOBBER_F);
     else if constexpr (MODE == MODE_BDST)
         asm volatile("ds_read_b128 v[124:127], %0\n\tds_read_b128 v[128:131], %1\n\t"
@@ -404,37 +440,56 @@ __device__ __forceinline__ void ak_state_store(unsigned own, unsigned oth, unsig
 }
 
 // Static sites of a pass (compile-time recursion: the entry registers must be indexed by constants).  `cur` holds GS K
-// steps from the group of the pass's first step on; the pass walks steps [ra, rb) of them, 0 <= ra < GS, rb <= GS K.
-// hook(S) runs at every site whether the site is walked or not: what it issues (the next block's entries, one
-// conditional load per site) sits at fixed program points.
+// steps from the group of the pass's first step on; the pass walks steps [ra, rb) of them, 0 <= ra < GS, ra < rb <= GS K:
+// sites ra + 1 .. rb.  hook(S) runs for every S = 0 .. GS K whether site S is walked or not: what it issues (the next block's
+// entries, one conditional load per site) sits at fixed program points of the walk.  The chain is LEFT behind the last step (it
+// returns the S it stopped at) and ak_tail runs the hooks from there on, one copy for all exits -- every instruction of a
+// wavefront costs an issue slot, scalar ones too.
+template <int S, int K, class FH>
+__device__ __forceinline__ void ak_tail(int from, FH&& hook) {
+    if constexpr (S <= 4 * K) {
+        if (S >= from) hook(std::integral_constant<int, S>());      // (the hooks that do nothing fold away with their test)
+        ak_tail<S + 1, K>(from, hook);
+    }
+}
 template <int MODE, int S, int K, class Cur, class FH>
-__device__ __forceinline__ void ak_sites(int ra, int rb, const Cur& cur, AkConst& c, FH&& hook) {
+__device__ __forceinline__ int ak_sites(int ra, int rb, const Cur& cur, AkConst& c, FH&& hook) {
     constexpr int GS = 4, N = GS * K;
     if constexpr (S <= N) {
-        constexpr int g = (S < N ? S : N - 1) / GS, gp = (S > 0 ? S - 1 : 0) / GS;
-        const int o = cur[g].o;                                                   // offsets of step S (S < N)
-        const int v = ((S - 1) & 1) ? cur[gp].v1 : cur[gp].v0;                    // value of step S - 1 (S > 0)
-        if constexpr (S < GS) {
-            if (S < rb) {
-                if (S > ra) { if constexpr (S > 0) ak_site<MODE, S & 3, 0>(o, v, c); }
-                else if (S == ra) ak_site<MODE, S & 3, 1>(o, 0, c);
-            } else if (S == rb && rb > ra) {
-                if constexpr (S > 0) ak_site<MODE, S & 3, 2>(0, v, c);
-            }
-        } else if constexpr (S < N) {
-            if (__builtin_expect(S < rb, 1)) ak_site<MODE, S & 3, 0>(o, v, c);
-            if (__builtin_expect(S == rb, 0)) ak_site<MODE, S & 3, 2>(0, v, c);
-        } else {
-            if (S == rb) ak_site<MODE, S & 3, 2>(0, v, c);
+        constexpr int gr = (S + 1 < N ? S + 1 : N - 1) / GS, gp = (S - 1) / GS;
+        // (ONE call of the next level per level: two would double the code of everything behind them)
+        if (S > GS || S > ra) {             // (the first group: the pass starts at step ra, its first site is ra + 1)
+            if (__builtin_expect(S > rb, 0)) return S;
+            ak_site<MODE, S & 3>(cur[gr].o, ((S - 1) & 1) ? cur[gp].v1 : cur[gp].v0, c);
         }
         hook(std::integral_constant<int, S>());
-        ak_sites<MODE, S + 1, K>(ra, rb, cur, c, hook);
+        return ak_sites<MODE, S + 1, K>(ra, rb, cur, c, hook);
+    } else {
+        return S;
     }
+}
+// the whole pass (rb > ra): the reads of the first two steps, the walk, then the hooks behind its end
+template <int MODE, int K, class Cur, class FH, class FT>
+__device__ __forceinline__ void ak_walk(int ra, int rb, const Cur& cur, AkConst& c, FH&& hook, FT&& tick) {
+    if (rb > ra) {
+        const int o0 = cur[0].o, o1 = cur[K > 1 ? 1 : 0].o;
+        if (ra == 0) ak_prologue<MODE, 0>(o0, o0, c);
+        else if (ra == 1) ak_prologue<MODE, 1>(o0, o0, c);
+        else if (ra == 2) ak_prologue<MODE, 2>(o0, o0, c);
+        else ak_prologue<MODE, 3>(o0, o1, c);
+    }
+    tick(2);
+    hook(std::integral_constant<int, 0>());
+    const int ex = rb > ra ? ak_sites<MODE, 1, K>(ra, rb, cur, c, hook) : 1;
+    tick(3);
+    ak_tail<1, K>(ex, hook);
+    tick(4);
 }
 
 // (the kernels below declare the LDS block and call this; the asm addresses LDS by absolute byte offsets, so the block must
 // be the kernel's only __shared__ object: checked at run time, one scalar compare)
-template <int MODE>
+// STAMP (timing build only): cycle counters per phase instead of the results (tools/attn_stream_cycles.py)
+template <int MODE, bool STAMP = false>
 __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const AttnArgs& a, char* smem) {
     using M = AM<MODE>;
     using G = typename M::G;
@@ -446,6 +501,26 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
     const int row0 = t.tile_row[tile];
     const int n_rows = t.tile_row[tile + 1] - row0;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned cyc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned last_ = STAMP ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    const unsigned start_ = last_;
+#define AK_TICK(K)                                                      \
+    if (STAMP) {                                                        \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();   \
+        cyc[K] += now_ - last_;                                         \
+        last_ = now_;                                                   \
+    }
+
+    // (detail variant of the stamps, -DMLLP_AK_STAMP_DETAIL: [1] top of the block, [2] start of a pass (addresses, state
+    // loads, first reads), [3] the chain of sites, [4] hooks behind the walk + refills, [5] end of a pass (check, state
+    // store) + wait for the prefetch + barrier)
+#ifdef MLLP_AK_STAMP_DETAIL
+#define AK_TICKC(K)
+#define AK_TICKD(K) AK_TICK(K)
+#else
+#define AK_TICKC(K) AK_TICK(K)
+#define AK_TICKD(K)
+#endif
 
     // ---- the tile's state ----
     if constexpr (MODE == MODE_FWD) {       // q' and t in log2 units, Z = 0, {L, u, m} = 0
@@ -519,20 +594,24 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
                 const int piece = d + A_STAGERS * i;
-                if (piece * 1024 + lane * 16 < nbytes)
+                if (piece * 1024 + lane * 16 < nbytes && !(AK_ABL & 4))
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(src + piece * 1024),
                         (__attribute__((address_space(3))) void*)(img_base + piece * 1024), 16, 0, 0);
-                if (paced) __builtin_amdgcn_s_sleep(MLLP_AK_SLEEP);      // a burst would block the walkers in their own loads
+                if (paced && !(AK_ABL & 32)) __builtin_amdgcn_s_sleep(MLLP_AK_SLEEP);      // a burst would block the walkers in their own loads
             }
         };
         if (nb > 0) stage(0, 0, false);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        AK_TICK(0)
         for (int k = 0; k < nb; ++k) {
             if (k + 1 < nb) stage(k + 1, (k + 1) & 1, true);
+            AK_TICK(1)
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the pieces have landed
+            AK_TICK(2)
             __syncthreads();
+            AK_TICK(3)
         }
     } else {
         // ------------------------------------------------ walkers -------------------------------------------------
@@ -571,17 +650,12 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
         auto slow_pass = [&](int rr, int a0, int b0, unsigned img) {
             if constexpr (MODE == MODE_FWD) {
                 if (part < 2) {
+                    // (few registers on purpose: the row's q' and Z stay in LDS, 16 bytes at a time -- this path is rare and
+                    // shares the kernel's 120 registers with the entry sets of the fast path)
                     const int row = min((rr >> (16 * part)) & 0xffff, G::RR);
-                    float q[16], z[16];
-                    float4* Q = reinterpret_cast<float4*>(smem + M::QA) + row * 4;
+                    const float4* Q = reinterpret_cast<const float4*>(smem + M::QA) + row * 4;
                     float4* Zs = reinterpret_cast<float4*>(smem + M::ZA) + row * 4;
                     float4* St = reinterpret_cast<float4*>(smem + M::SA) + row;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 qq = Q[i], zz = Zs[i];
-                        q[4 * i] = qq.x; q[4 * i + 1] = qq.y; q[4 * i + 2] = qq.z; q[4 * i + 3] = qq.w;
-                        z[4 * i] = zz.x; z[4 * i + 1] = zz.y; z[4 * i + 2] = zz.z; z[4 * i + 3] = zz.w;
-                    }
                     const float4 st = *St;
                     float L = st.x, u = st.y, m = st.z;
                     const float tq = st.w;
@@ -591,33 +665,30 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
                         if (off == G::ZERO_OFF) continue;
                         const float av = __int_as_float(e[1 + (s & 1)]);
                         const float4* xs = reinterpret_cast<const float4*>(smem + img + off);
-                        float x[16];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 xx = xs[i];
-                            x[4 * i] = xx.x; x[4 * i + 1] = xx.y; x[4 * i + 2] = xx.z; x[4 * i + 3] = xx.w;
-                        }
-                        const float l = fmaf(av, tq, dot16(q, x, 0.0f));
+                        float l = av * tq;
+#pragma unroll 1
+                        for (int i = 0; i < 4; ++i) l += dot4(Q[i], xs[i]);
+                        float cs = 1.0f;
                         if (L == 0.0f) {
                             m = l;
                         } else if (l > m) {
-                            const float cs = __builtin_amdgcn_exp2f(m - l);
+                            cs = __builtin_amdgcn_exp2f(m - l);
                             L *= cs; u *= cs;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) z[i] *= cs;
                             m = l;
                         }
                         const float p = __builtin_amdgcn_exp2f(l - m);
                         L += p;
                         u = fmaf(p, av, u);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) z[i] = fmaf(p, x[i], z[i]);
+#pragma unroll 1
+                        for (int i = 0; i < 4; ++i) {
+                            float4 z = Zs[i];
+                            const float4 x = xs[i];
+                            z.x = fmaf(p, x.x, z.x * cs); z.y = fmaf(p, x.y, z.y * cs);
+                            z.z = fmaf(p, x.z, z.z * cs); z.w = fmaf(p, x.w, z.w * cs);
+                            if (row < G::RR) Zs[i] = z;
+                        }
                     }
-                    if (row < G::RR) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) Zs[i] = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
-                        *St = make_float4(L, u, m, tq);
-                    }
+                    if (row < G::RR) *St = make_float4(L, u, m, tq);
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): no compiler-tracked LDS operation stays pending
             }
@@ -638,17 +709,17 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
             if constexpr (MODE == MODE_BDST) sc = (unsigned)(M::SA + r_own * 32);
             AkConst c;
             c.pb = img + part * 16; c.pz = c.pb + G::ZERO_OFF; c.pbs = img + 128; c.ninf = (int)0xff800000u;
-            c.k = MODE == MODE_BSRC ? A_LOG2E : 64.0f;
-            c.viol = c.real_e = c.real_o = 0ull;
-            if (any) ak_state_load<MODE>(own, oth, sc);
-            ak_sites<MODE, 0, K>(ra, any ? min(rb, G::GS * K) : ra, cur, c, [&](auto hc_) {
+            c.k = A_LOG2E;
+            c.real_e = c.real_o = 0ull;
+            if (any && !(AK_ABL & 8)) ak_state_load<MODE>(own, oth, sc);
+            ak_walk<MODE, K>(ra, any ? min(rb, G::GS * K) : ra, cur, c, [&](auto hc_) {
                 constexpr int site = decltype(hc_)::value;
                 constexpr int h = site - G::GS;             // site of the last arithmetic of group h / GS
                 if constexpr (h >= 0 && h % G::GS == 0 && h / G::GS < K) {
-                    if (__builtin_expect(h / G::GS < gn, 1)) cur[h / G::GS] = ld3(np + 64 * (h / G::GS));
+                    if (__builtin_expect(h / G::GS < gn, 1) && !(AK_ABL & 16)) cur[h / G::GS] = ld3(np + 64 * (h / G::GS));
                 }
                 extra(hc_);
-            });
+            }, [&](int k_) { (void)k_; AK_TICKD(k_) });
             if (__builtin_expect(rb > G::GS * K, 0)) {
                 // rare: the pass is longer than its register set (a row with dozens of entries inside one block): the rest
                 // runs on groups that are loaded here, K1 at a time -- the same sites, the state stays in the registers
@@ -657,12 +728,16 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
                     Ent3 tmp[G::K1];
 #pragma unroll
                     for (int j = 0; j < G::K1; ++j) tmp[j] = ld3(base + 64 * (s0 / G::GS + j));
-                    ak_sites<MODE, 0, G::K1>(0, min(rb - s0, G::GS * G::K1), tmp, c, [&](auto) {});
+                    ak_walk<MODE, G::K1>(0, min(rb - s0, G::GS * G::K1), tmp, c, [&](auto) {}, [&](int) {});
                 }
             }
             bool redo = false;
-            if constexpr (MODE == MODE_FWD) redo = c.viol != 0ull;
-            if (any && !redo) ak_state_store<MODE>(own, oth, sc);
+            if constexpr (MODE == MODE_FWD) {       // did |l - m| leave the window of the fast pass in any lane?
+                unsigned long long out;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_cmp_gt_f32_e64 %0, v165, %1" : "=s"(out) : "s"(64.0f) : AK_CLOBBER_F);
+                redo = any && out != 0ull && AK_ABL == 0;       // (an ablated walk computes on garbage: no redo)
+            }
+            if (any && !redo && !(AK_ABL & 8)) ak_state_store<MODE>(own, oth, sc);
             if (any && redo) {
                 asm volatile("; SK_SLOW_BEGIN" : : : "memory");
                 slow_pass(rr, a0, b0, img);
@@ -672,6 +747,7 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
 
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the first entries have landed
         __syncthreads();                         // image 0 and the tile's state are in LDS
+        AK_TICK(0)
         auto block = [&](int k, auto& ebc, auto& ebn) {
             const i32x4 rn = __builtin_nontemporal_load(rowp + 16 * G::NW * min(k + 1, nb - 1));
             const i32x4 h2 = hdrp[G::NW * min(k + 2, nb - 1)];
@@ -686,24 +762,49 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
             const unsigned c_ = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
             const int n0_ = (int)(c_ & 0xffffu), n1_ = (int)(c_ >> 16);
             const unsigned img = (unsigned)((k & 1) * M::IMG);
+            AK_TICK(1)
             pass(ea, npa, gna, std::integral_constant<int, G::K0>(), rc.x, S_, S_ + n0_, img, [&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 if constexpr (s % 2 == 0 && s / 2 < G::K1) {     // the next block's pass-1 entries, one group per even site
-                    if (__builtin_expect(s / 2 < gnb, 1)) ebn[s / 2] = ld3(npb + 64 * (s / 2));
+                    if (__builtin_expect(s / 2 < gnb, 1) && !(AK_ABL & 16)) ebn[s / 2] = ld3(npb + 64 * (s / 2));
                 }
             });
+            AK_TICKC(2)
             pass(ebc, npb, 0, std::integral_constant<int, G::K1>(), rc.z, S_ + n0_, S_ + n0_ + n1_, img, [&](auto) {});
+            AK_TICKC(3)
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next entries have landed
             rc = rn; hc = hn; hn = h2;
+            AK_TICKC(4)
             __syncthreads();
+            AK_TICK(5)
         };
-        for (int k = 0; k < nb; k += 2) {
+        for (int k = 0; k < nb; ++k) {       // (one copy of the block body: the pass-1 sets change roles by a register copy)
             block(k, eb, eb2);
-            if (k + 1 >= nb) break;
-            block(k + 1, eb2, eb);
+#pragma unroll
+            for (int j = 0; j < G::K1; ++j) eb[j] = eb2[j];
         }
     }
     // (the last barrier of the loop made every wavefront's state visible)
+    if constexpr (STAMP) {
+        // stamps instead of the result: row 2 * tile of the output = the walkers' sums {[0] init, [1] top of the block, [2] pass
+        // 0, [3] pass 1, [4] wait for the prefetch, [5] barrier, [6] total}, row 2 * tile + 1 = the stagers' {[0] init, [1] issue,
+        // [2] wait for the pieces, [3] barrier, [6] total}
+        const unsigned total_ = (unsigned)__builtin_amdgcn_s_memtime() - start_;
+        __syncthreads();
+        int* acc = reinterpret_cast<int*>(smem);
+        if (tid < 32) acc[tid] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            const int o = wave >= G::NW ? 16 : 0;
+            for (int k = 0; k < 6; ++k) atomicAdd(&acc[o + k], (int)cyc[k]);
+            atomicAdd(&acc[o + 6], (int)total_);
+        }
+        __syncthreads();
+        float* out = MODE == MODE_FWD ? a.h : MODE == MODE_BDST ? a.dqp : a.dx;
+        if (tid < 32 && 2 * tile + 1 < t.n_dst) out[(size_t)(2 * tile) * 16 + tid] = (float)acc[tid];
+        return;
+    }
+#undef AK_TICK
 
     if constexpr (MODE == MODE_FWD) {
         // ---- epilogue: 16 lanes per row (lane gl = output channel) ----
@@ -799,6 +900,24 @@ __global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_num_vgpr(94))) voi
     attn_stream_body<MODE_BSRC>(t, a, smem);
 }
 static_assert(AM<MODE_FWD>::VGPRS == 120 && AM<MODE_BDST>::VGPRS == 106 && AM<MODE_BSRC>::VGPRS == 94, "the literals above");
+#ifdef MLLP_TIMING_BUILD
+__global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_num_vgpr(120))) void fwd16_stream_stamps(AttnStreamDev t, AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[AM<MODE_FWD>::LDS + 256];
+    attn_stream_body<MODE_FWD, true>(t, a, smem);
+}
+__global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_num_vgpr(106))) void bwddst16_stream_stamps(AttnStreamDev t, AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[AM<MODE_BDST>::LDS + 256];
+    attn_stream_body<MODE_BDST, true>(t, a, smem);
+}
+__global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_num_vgpr(94))) void bwdsrc16_stream_stamps(AttnStreamDev t, AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[AM<MODE_BSRC>::LDS + 256];
+    attn_stream_body<MODE_BSRC, true>(t, a, smem);
+}
+static bool attn_stamps() { const char* e = getenv("MLLP_ATTN_STAMPS"); return e && atoi(e) != 0; }
+#define AK_LAUNCH(K, KS, ...) hipLaunchKernelGGL(attn_stamps() ? KS : K, __VA_ARGS__)
+#else
+#define AK_LAUNCH(K, KS, ...) hipLaunchKernelGGL(K, __VA_ARGS__)
+#endif
 
 AttnStreamDev stream_dev(const StreamCopy& sc, int n_dst, int n_src) {
     AttnStreamDev t;
@@ -821,7 +940,7 @@ int launch_fwd16_stream(const StreamCopy& sc, int n_dst, int n_src, const float*
     AttnArgs a = {};
     a.items = x_src; a.xd = x_dst; a.qp = w.qp; a.tq = w.t; a.p = conv_params_at(conv_params, 16);
     a.h = h_out; a.Z = w.Z; a.aux = w.aux;
-    hipLaunchKernelGGL(fwd16_stream_kernel, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_dst, n_src), a);
+    AK_LAUNCH(fwd16_stream_kernel, fwd16_stream_stamps, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_dst, n_src), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "fwd16_stream");
 }
@@ -832,7 +951,7 @@ int launch_bwddst16_stream(const StreamCopy& sc, int n_dst, int n_src, const Con
     AttnArgs a = {};
     a.items = x_src; a.rec = w.rec; a.g = g; a.derived = w.derived; a.dqp = w.dqp; a.dsdt = w.dsdt; a.dx = dx_dst;
     a.accumulate = accumulate;
-    hipLaunchKernelGGL(bwddst16_stream_kernel, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_dst, n_src), a);
+    AK_LAUNCH(bwddst16_stream_kernel, bwddst16_stream_stamps, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_dst, n_src), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwddst16_stream");
 }
@@ -843,7 +962,7 @@ int launch_bwdsrc16_stream(const StreamCopy& sc, int n_rows, int n_cols, const f
     if (n_rows == 0 || sc.n_tiles == 0) return MLLP_OK;
     AttnArgs a = {};
     a.items = rec; a.x_rows = x_rows; a.dx = dx; a.accumulate = accumulate;
-    hipLaunchKernelGGL(bwdsrc16_stream_kernel, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_rows, n_cols), a);
+    AK_LAUNCH(bwdsrc16_stream_kernel, bwdsrc16_stream_stamps, dim3((unsigned)sc.n_tiles), dim3(A_THREADS), 0, s, stream_dev(sc, n_rows, n_cols), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "bwdsrc16_stream");
 }

@@ -105,13 +105,15 @@ class LPTrainer:
     # per-instance loop is slower replayed (6.0 k vs 7.6 k instances/s).  `use_hip_graph=True` still forces capture.
     GRAPH_NNZ_LIMIT = 0
 
-    # "auto": batches of at least this many nonzeros get the LDS-tiled copies of the attention sweeps, both orientations
-    # (LPBatch.enable_tiled_step: the throughput regime of the library's row tiers starts at the same size); smaller ones
-    # run the fused latency-regime kernels
+    # "auto": batches of at least this many nonzeros get the re-blocked copies of the attention sweeps, both orientations
+    # (the throughput regime of the library's row tiers starts at the same size): the STREAMED copies for the 16-channel
+    # sweeps (round 4, LPBatch.enable_stream_step) and the LDS-tiled variant 3 for the 1-channel sweeps of layer 1; with
+    # `stream_copies=False` all sweeps run on LDS-tiled copies (round 2-3, LPBatch.enable_tiled_step); smaller batches run
+    # the fused latency-regime kernels
     TILED_NNZ_MIN = 32 << 20
 
     def __init__(self, params_flat: torch.Tensor, lr=1e-3, use_hip_graph="auto",
-                 global_instances: Optional[int] = None, with_metrics=False, tiled_copies="auto"):
+                 global_instances: Optional[int] = None, with_metrics=False, tiled_copies="auto", stream_copies=True):
         assert params_flat.is_cuda and params_flat.numel() == NUM_PARAMS
         self.params = params_flat.detach().clone().float().contiguous()
         self.opt = FlatAdam(self.params, lr=lr)
@@ -119,6 +121,7 @@ class LPTrainer:
         self.global_instances = global_instances
         self.with_metrics = with_metrics
         self.tiled_copies = tiled_copies
+        self.stream_copies = stream_copies
         self._plans = {}
         self._gen = 0                  # bumped at every library-side write of the parameters (LPBatch.train_step)
 
@@ -130,7 +133,13 @@ class LPTrainer:
             graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
             want_tiled = (batch.nnz >= self.TILED_NNZ_MIN) if self.tiled_copies == "auto" else bool(self.tiled_copies)
             if want_tiled and not getattr(batch, "_tiled", None):
-                batch.enable_tiled_step()
+                if self.stream_copies:
+                    if not getattr(batch, "_streams", None):
+                        batch._streams = batch.enable_stream_step()
+                    for tr in (False, True):
+                        batch.enable_tiled(tr, variant=3)
+                else:
+                    batch.enable_tiled_step()
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),
                      g_fwd=None, g_opt=None, warm=0, graph=graph)

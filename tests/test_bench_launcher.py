@@ -71,7 +71,33 @@ def test_bench_json_contract_on_the_gpu():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
     k0 = rf["kernels"][0]
     assert abs(k0["GBps"] - k0["alg_bytes"] / k0["ms"] / 1e6) < 1e-6 * k0["GBps"] and k0["max_rel_diff_vs_generic"] < 2e-6
-    assert d["synthetic"]["logits_max_rel_diff_tiled_vs_generic"] < 5e-6 and d["synthetic"]["tiled_build_s"] > 0
+    assert d["synthetic"]["logits_max_rel_diff_streamed_vs_generic"] < 5e-6 and d["synthetic"]["tiled_build_s"] > 0
+    assert d["synthetic"]["stream_build_s"] > 0 and d["synthetic"]["parity_gates"]["failed"] == [] and d["parity_gate_failures"] == []
+    # both orientations of the attention conv, forward and backward, generic / LDS-tiled / streamed, with their parity figures
+    names = [k["kernel"] for k in rf["kernels"]]
+    for label in ("dst=constraints", "dst=variables"):
+        for what in ("tconv_fwd16 generic", "tconv_bwd16 generic", "tconv_fwd16 LDS-tiled", "tconv_bwd16 LDS-tiled",
+                     "tconv_fwd16 streamed", "tconv_bwd16 streamed"):
+            assert any(n.startswith(what) and n.endswith(label) for n in names), (what, label)
+    for k in rf["kernels"]:
+        if k["kernel"].startswith("tconv_fwd16 streamed"):
+            assert k["max_rel_diff_vs_generic"] < 2e-6 and 0.05 < k["frac"] < 1.0
+        if k["kernel"].startswith("tconv_bwd16 streamed"):
+            assert max(k["max_rel_diff_vs_generic"].values()) < 5e-6
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
     assert d["value"] > 100 * cb["value"]
+
+
+@pytest.mark.gpu
+def test_bench_exits_nonzero_when_a_parity_gate_fails():
+    """the full-size parity figures are gates.  A deliberately perturbed comparison (MLLP_BENCH_PERTURB adds
+    to the measured SpMM difference) still prints the JSON line, lists the failed gate and exits 1."""
+    env = dict(os.environ, MLLP_BENCH_PERTURB="1e-3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--synthetic-instances", "17", "--synthetic-steps", "1", "--spmm-reps", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert any("spmm_stream A*H" in f for f in d["parity_gate_failures"])
+    assert "parity gate" in r.stderr

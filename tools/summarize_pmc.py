@@ -8,7 +8,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("void mllp::", "")
+            k = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void mllp::", "").replace("mllp::", "")
             if filt not in k:
                 continue
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

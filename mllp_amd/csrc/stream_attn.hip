@@ -134,9 +134,10 @@ struct AkConst {      // per-lane / per-wavefront constants and the running flag
     int ninf;                     // -inf
     float k;                      // source-major backward: log2(e)
     unsigned long long real_e, real_o;
+    unsigned long long seen;      // forward: lanes whose own row had a real entry in this pass
 };
 #define AK_CLOBBER_TOP                                                                                                \
-    "memory", "vcc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",   \
+    "memory", "vcc", "scc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",   \
         "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147",      \
         "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161",      \
         "v162", "v163", "v164", "v165", "v166", "v167"
@@ -170,7 +171,7 @@ constexpr int AK_ABL = 0;
 //   v152 L   v153 u   v154 m   v155 t            (the lane's own row)
 //   v156  the lane's offsets of the step to read        v158  LDS address        v159  partial sum -> logit -> l - m
 //   v[160:161] v[162:163]   dot-product pairs, then a t - m (v161), the other pair's partial (v162), a (v163)
-//   v164 p (own row; v[164:165] as pk_fma operand, which reads the low half only)   v165 running max of |l - m| of the pass
+//   v164 p (own row; v[164:165] as pk_fma operand, which reads the low half only)
 //   v[166:167] p of the other row
 // A site = the arithmetic of step S - 1, then the reads of step S + 1 into the registers that step S - 1 has just left: the
 // reads run TWO steps ahead on two register sets, every step has ONE copy of its code (a first version with separate
@@ -178,16 +179,17 @@ constexpr int AK_ABL = 0;
 // cache that two CUs share holds 64 KB, and a site took 600 cycles whatever it contained -- profiles/r04_attn_stream_cycles.txt).
 // The pass starts with the reads of its first two steps (AK_PRO) and ends with two reads too many (of whatever follows in
 // the stream: harmless, waited for before the state is stored).
-#define FK_READS(OFFR, XR0, XR1, OWNR, OTHR, REALR)                                                       \
-    "v_add_u32_dpp v158, " OFFR ", %[pb]" OWNR AK_DSREAD("ds_read_b128 " XR0 ", v158\n\t") AK_REAL(REALR, "v158")     \
+#define FK_ADR0(OFFR, OWNR) "v_add_u32_dpp v158, " OFFR ", %[pb]" OWNR
+#define FK_READS_(OFFR, XR0, XR1, OTHR, REALR)      /* (the first address is in v158 already) */                     \
+    AK_DSREAD("ds_read_b128 " XR0 ", v158\n\t") AK_REAL(REALR, "v158")                                             \
     "v_add_u32_dpp v158, " OFFR ", %[pb]" OTHR AK_DSREAD("ds_read_b128 " XR1 ", v158\n\t")
+#define FK_READS(OFFR, XR0, XR1, OWNR, OTHR, REALR) FK_ADR0(OFFR, OWNR) FK_READS_(OFFR, XR0, XR1, OTHR, REALR)
 #define FK_DOT(C0L, C0H, C1L, C1H)                                                                        \
     AK_PKMUL("v[160:161]", C0L, "v[136:137]") AK_PKMUL("v[162:163]", C1L, "v[140:141]")                  \
     AK_PKFMA("v[160:161]", C0H, "v[138:139]") AK_PKFMA("v[162:163]", C1H, "v[142:143]")
 // partial sums of the own / the other row; a of the own row; both summed over the lane pair; a t - m; (OFFN); + the other
-// pair's sum of the own row; l - m; padding -> -inf; p = 2^(l - m); running max of |l - m| (also the wait state of the
-// exponential); L, u; the other row's p; Z
-#define FK_RED(OWNC, OFFN, REALC)                                         \
+// pair's sum of the own row; l - m; padding -> -inf; p = 2^(l - m) (+ its wait state); L, u; the other row's p; Z
+#define FK_RED(OWNC, OFFN, REALC, ADR0)                                   \
     AK_ARITH("v_add_f32 v159, v160, v161\n\t"                             \
     "v_add_f32 v162, v162, v163\n\t"                                      \
     "v_mov_b32_dpp v163, %[val]" OWNC                                     \
@@ -197,8 +199,8 @@ constexpr int AK_ABL = 0;
     AK_ARITH("v_add_f32_dpp v159, v162, v159" AK_QP(2, 3, 0, 1)           \
     "v_add_f32 v159, v159, v161\n\t"                                      \
     "v_cndmask_b32_e64 v164, %[ninf], v159, " REALC "\n\t"                \
-    "v_exp_f32_e32 v164, v164\n\t"                                        \
-    "v_max_f32_e64 v165, v165, |v159|\n\t")
+    "s_or_b64 %[seen], %[seen], " REALC "\n\t"                            \
+    "v_exp_f32_e32 v164, v164\n\t") ADR0
 #define FK_ACC(C0L, C0H, C1L, C1H)                                        \
     "v_add_f32 v152, v152, v164\n\t"                                      \
     "v_fmac_f32 v153, v164, v163\n\t"                                     \
@@ -206,8 +208,8 @@ constexpr int AK_ABL = 0;
     AK_PKACC("v[144:145]", "v[164:165]", C0L) AK_PKACC("v[146:147]", "v[164:165]", C0H) \
     AK_PKACC("v[148:149]", "v[166:167]", C1L) AK_PKACC("v[150:151]", "v[166:167]", C1H)
 #define FK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)                          \
-    "s_waitcnt lgkmcnt(2)\n\t" AK_ARITH(FK_DOT(C0L, C0H, C1L, C1H)) FK_RED(OWNC, OFFN, REALC)              \
-        AK_ARITH(FK_ACC(C0L, C0H, C1L, C1H)) FK_READS("v156", XR0, XR1, OWNR, OTHR, REALR)
+    "s_waitcnt lgkmcnt(2)\n\t" AK_ARITH(FK_DOT(C0L, C0H, C1L, C1H)) FK_RED(OWNC, OFFN, REALC, FK_ADR0("v156", OWNR)) \
+        AK_ARITH(FK_ACC(C0L, C0H, C1L, C1H)) FK_READS_("v156", XR0, XR1, OTHR, REALR)
 #define FK_PRO(OFFA, XA0, XA1, OWNA, OTHA, REALA, OFFB, XB0, XB1, OWNB, OTHB, REALB)                       \
     OFFA "s_nop 1\n\t" FK_READS("v156", XA0, XA1, OWNA, OTHA, REALA) OFFB "s_nop 1\n\t" FK_READS("v156", XB0, XB1, OWNB, OTHB, REALB)
 #define FK_E "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]"
@@ -335,7 +337,7 @@ constexpr int AK_ABL = 0;
 #define DK_SITE_(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) DK_SITE_X(C, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
 #define DK_SITE_X(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR) DK_SITE(C0L, C0H, C1L, C1H, OWNC, REALC, OFFN, XR0, XR1, OWNR, OTHR, REALR)
 
-#define AK_IO_(CLOB) : [re] "+s"(c.real_e), [ro] "+s"(c.real_o) \
+#define AK_IO_(CLOB) : [re] "+s"(c.real_e), [ro] "+s"(c.real_o), [seen] "+s"(c.seen) \
                      : [oa] "v"(oa), [ob] "v"(ob), [val] "v"(val), [pb] "v"(c.pb), [pz] "v"(c.pz), [pbs] "v"(c.pbs), [k] "s"(c.k), [ninf] "v"(c.ninf) : CLOB
 // Site S (S counted from the first step of the register set's first group; S4 = S mod 4): arithmetic of step S - 1 (`val`: the
 // lane's value of that step), reads of step S + 1 (`ob`: the lane's offset word of the group of step S + 1).
@@ -409,7 +411,7 @@ __device__ __forceinline__ void ak_state_load(unsigned own, unsigned oth, unsign
     using M = AM<MODE>;
     if constexpr (MODE == MODE_FWD)
         asm volatile("ds_read_b128 v[136:139], %0\n\tds_read_b128 v[140:143], %1\n\t"
-                     "ds_read_b128 v[144:147], %2\n\tds_read_b128 v[148:151], %3\n\tds_read_b128 v[152:155], %4\n\tv_mov_b32 v165, 0"
+                     "ds_read_b128 v[144:147], %2\n\tds_read_b128 v[148:151], %3\n\tds_read_b128 v[152:155], %4"
                      : : "v"(own + M::QA), "v"(oth + M::QA), "v"(own + M::ZA), "v"(oth + M::ZA), "v"(sc) : AK_CLOBBER_F);
     else if constexpr (MODE == MODE_BDST)
         asm volatile("ds_read_b128 v[124:127], %0\n\tds_read_b128 v[128:131], %1\n\t"
@@ -710,7 +712,8 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
             AkConst c;
             c.pb = img + part * 16; c.pz = c.pb + G::ZERO_OFF; c.pbs = img + 128; c.ninf = (int)0xff800000u;
             c.k = A_LOG2E;
-            c.real_e = c.real_o = 0ull;
+            c.real_e = c.real_o = c.seen = 0ull;
+            asm volatile("" : "+v"(c.ninf), "+v"(c.pbs));     // (opaque: they stay in VGPRs instead of being re-made per site)
             if (any && !(AK_ABL & 8)) ak_state_load<MODE>(own, oth, sc);
             ak_walk<MODE, K>(ra, any ? min(rb, G::GS * K) : ra, cur, c, [&](auto hc_) {
                 constexpr int site = decltype(hc_)::value;
@@ -732,10 +735,16 @@ __device__ __forceinline__ void attn_stream_body(const AttnStreamDev& t, const A
                 }
             }
             bool redo = false;
-            if constexpr (MODE == MODE_FWD) {       // did |l - m| leave the window of the fast pass in any lane?
-                unsigned long long out;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_cmp_gt_f32_e64 %0, v165, %1" : "=s"(out) : "s"(64.0f) : AK_CLOBBER_F);
-                redo = any && out != 0ull && AK_ABL == 0;       // (an ablated walk computes on garbage: no redo)
+            if constexpr (MODE == MODE_FWD) {
+                // Did some l - m leave the window of the fast pass?  Not checked per step: a p = 2^(l - m) above 2^64 shows in L
+                // (L > 2^63 or inf; a slow pass leaves L <= the row's length, the fast passes behind it add p < 2^64 each), and a
+                // row ALL of whose p underflowed shows as L < 2^-63 with a real entry seen in this pass (single tiny p next to
+                // normal ones are below fp32's resolution of L anyway).  A NaN in L fails both tests: it belongs to the data.
+                unsigned long long hi, lo;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_cmp_gt_f32_e64 %0, v152, %2\n\tv_cmp_lt_f32_e64 %1, v152, %3\n\t"
+                             "s_and_b64 %1, %1, %4"
+                             : "=&s"(hi), "=&s"(lo) : "s"(9.223372e18f), "s"(1.0842022e-19f), "s"(c.seen) : AK_CLOBBER_F);
+                redo = any && (hi | lo) != 0ull && AK_ABL == 0;       // (an ablated walk computes on garbage: no redo)
             }
             if (any && !redo && !(AK_ABL & 8)) ak_state_store<MODE>(own, oth, sc);
             if (any && redo) {

@@ -1761,8 +1761,8 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((int64_t)g->h_csr_ptr.size() != g->M + 1 && !h_csr_ptr) return fail(MLLP_EINVAL, "fused path: no host row pointers");
     HostFusedOrient hc, hv;
     {
-        const std::vector<int> part = host_partition_instances(host_instance_cost(h_csr_ptr, g->h_inst_ptr_m),
-                                                               host_instance_cost(h_csc_ptr, g->h_inst_ptr_n), FUSED_PARTS);
+        const std::vector<int> part = host_partition_instances_v(host_instance_loads(h_csr_ptr, g->h_inst_ptr_m),
+                                                                 host_instance_loads(h_csc_ptr, g->h_inst_ptr_n), FUSED_PARTS);
         host_build_fused_orient(h_csr_ptr, (int)g->M, g->h_inst_ptr_m, part, &hc);     // constraints by (partition, row length)
         host_build_fused_orient(h_csc_ptr, (int)g->N, g->h_inst_ptr_n, part, &hv);     // variables by (partition, column length)
     }

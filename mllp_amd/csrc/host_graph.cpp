@@ -1,6 +1,8 @@
 // host_graph.cpp -- see host_graph.h.  Plain C++17, no HIP.
 #include "host_graph.h"
 
+#include <array>
+
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -150,6 +152,147 @@ std::vector<int64_t> host_instance_cost(const int* ptr, const std::vector<int64_
         cost[k] = c;
     }
     return cost;
+}
+
+std::vector<InstLoad> host_instance_loads(const int* ptr, const std::vector<int64_t>& inst_off) {
+    const size_t n = inst_off.empty() ? 0 : inst_off.size() - 1;
+    std::vector<InstLoad> out(n);
+    for (size_t k = 0; k < n; ++k) {
+        InstLoad& l = out[k];
+        for (int64_t r = inst_off[k]; r < inst_off[k + 1]; ++r) {
+            const int64_t deg = ptr[r + 1] - ptr[r];
+            // 16-channel geometry, in 1/16 of an item / of an item's step.  A block row (walked by the 12 wavefronts of a
+            // workgroup) is counted as FUSED_BLOCK_ROW_ITEMS items, not as a quantity of its own: normalised, the handful of
+            // such rows -- one instance owns half of them -- outweighed everything else (partitions at 14 k and at 64 k cycles)
+            if (deg > FUSED_T16[2]) { l.d[0] += 16 * FUSED_BLOCK_ROW_ITEMS; l.d[1] += 16 * 2 * ((deg + 767) / 768); l.d[4] += 1; }
+            else if (deg > FUSED_T16[1]) { l.d[0] += 16; l.d[1] += 16 * ((deg + 63) / 64); }
+            else if (deg > FUSED_T16[0]) { l.d[0] += 4; l.d[1] += 4 * ((deg + 15) / 16); }
+            else { l.d[0] += 1; l.d[1] += std::max<int64_t>((deg + 3) / 4, 1); }
+            // 1-channel geometry, in 1/64
+            if (deg > FUSED_T1[2]) { l.d[2] += 64 * FUSED_BLOCK_ROW_ITEMS; l.d[3] += 64 * 2 * ((deg + 6143) / 6144); }
+            else if (deg > FUSED_T1[1]) { l.d[2] += 64; l.d[3] += 64 * ((deg + 511) / 512); }
+            else if (deg > FUSED_T1[0]) { l.d[2] += 4; l.d[3] += 4 * ((deg + 31) / 32); }
+            else { l.d[2] += 1; l.d[3] += std::max<int64_t>((deg + 7) / 8, 1); }
+        }
+    }
+    return out;
+}
+
+namespace {
+struct VecBalance {
+    static constexpr int D = 2 * FUSED_LOAD_DIMS;
+    int n_parts;
+    std::vector<std::array<double, D>> x;       // normalised load of every instance: its share of the total, times n_parts
+    std::vector<std::array<double, D>> load;    // of every partition
+    double max_of(int q) const {
+        double m = 0.0;
+        for (int d = 0; d < D; ++d) m = std::max(m, load[(size_t)q][d]);
+        return m;
+    }
+    double worst() const {
+        double m = 0.0;
+        for (int q = 0; q < n_parts; ++q) m = std::max(m, max_of(q));
+        return m;
+    }
+};
+}  // namespace
+
+double host_partition_imbalance(const std::vector<InstLoad>& a, const std::vector<InstLoad>& b, const std::vector<int>& part,
+                                int n_parts) {
+    double worst = 0.0;
+    for (int side = 0; side < 2; ++side)
+        for (int d = 0; d < FUSED_LOAD_DIMS - 1; ++d) {
+            std::vector<double> l((size_t)n_parts, 0.0);
+            double tot = 0.0;
+            for (size_t i = 0; i < a.size(); ++i) {
+                const double v = (double)(side ? b[i].d[d] : a[i].d[d]);
+                l[(size_t)part[i]] += v;
+                tot += v;
+            }
+            if (tot <= 0.0) continue;
+            for (int q = 0; q < n_parts; ++q) worst = std::max(worst, l[(size_t)q] * n_parts / tot);
+        }
+    return worst;
+}
+
+std::vector<int> host_partition_instances_v(const std::vector<InstLoad>& a, const std::vector<InstLoad>& b, int n_parts) {
+    const int n = (int)a.size();
+    constexpr int D = VecBalance::D;
+    VecBalance vb;
+    vb.n_parts = n_parts;
+    vb.x.assign((size_t)n, std::array<double, D>{});
+    vb.load.assign((size_t)n_parts, std::array<double, D>{});
+    double tot[D] = {};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < FUSED_LOAD_DIMS; ++d) { tot[d] += (double)a[i].d[d]; tot[FUSED_LOAD_DIMS + d] += (double)b[i].d[d]; }
+    // (d[4], the number of block rows, is informational: they are counted as items above; a quantity that is absent weighs
+    // nothing)
+    std::vector<double> size((size_t)n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < D; ++d) {
+            const double v = (double)(d < FUSED_LOAD_DIMS ? a[i].d[d] : b[i].d[d - FUSED_LOAD_DIMS]);
+            vb.x[(size_t)i][d] = tot[d] > 0.0 && d % FUSED_LOAD_DIMS != 4 ? v * n_parts / tot[d] : 0.0;
+            size[(size_t)i] = std::max(size[(size_t)i], vb.x[(size_t)i][d]);
+        }
+    std::vector<int> order((size_t)n), part((size_t)n, 0);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return size[(size_t)p] > size[(size_t)q]; });
+    std::vector<int> count((size_t)n_parts, 0);
+    for (int i : order) {
+        int best = 0;
+        double best_v = 0.0;
+        for (int q = 0; q < n_parts; ++q) {
+            double v = 0.0;
+            for (int d = 0; d < D; ++d) v = std::max(v, vb.load[(size_t)q][d] + vb.x[(size_t)i][d]);
+            // (empty instances -- all quantities zero -- are spread by count)
+            if (q == 0 || v < best_v - 1e-12 || (v < best_v + 1e-12 && count[(size_t)q] < count[(size_t)best])) { best = q; best_v = v; }
+        }
+        part[(size_t)i] = best;
+        count[(size_t)best]++;
+        for (int d = 0; d < D; ++d) vb.load[(size_t)best][d] += vb.x[(size_t)i][d];
+    }
+    // improvement: move an instance out of the worst partition, or swap it with one of another partition, while the
+    // largest load over all partitions and quantities goes down (bounded: a few hundred instances at most matter)
+    if (n <= 4096) {
+        for (int round = 0; round < 200; ++round) {
+            int wq = 0;
+            for (int q = 1; q < n_parts; ++q)
+                if (vb.max_of(q) > vb.max_of(wq)) wq = q;
+            const double cur = vb.max_of(wq);
+            double best_gain = 1e-9;
+            int bi = -1, bj = -1, bq = -1;
+            auto pair_max = [&](int q1, int q2, int i, int j) {      // max load of q1, q2 after i (of q1) <-> j (of q2, or -1)
+                double m = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double xi = vb.x[(size_t)i][d], xj = j >= 0 ? vb.x[(size_t)j][d] : 0.0;
+                    m = std::max(m, std::max(vb.load[(size_t)q1][d] - xi + xj, vb.load[(size_t)q2][d] + xi - xj));
+                }
+                return m;
+            };
+            for (int i = 0; i < n; ++i) {
+                if (part[(size_t)i] != wq) continue;
+                for (int q = 0; q < n_parts; ++q) {
+                    if (q == wq) continue;
+                    const double m0 = pair_max(wq, q, i, -1);
+                    if (cur - m0 > best_gain) { best_gain = cur - m0; bi = i; bj = -1; bq = q; }
+                    for (int j = 0; j < n; ++j) {
+                        if (part[(size_t)j] != q) continue;
+                        const double m1 = pair_max(wq, q, i, j);
+                        if (cur - m1 > best_gain) { best_gain = cur - m1; bi = i; bj = j; bq = q; }
+                    }
+                }
+            }
+            if (bi < 0) break;
+            for (int d = 0; d < D; ++d) {
+                const double xi = vb.x[(size_t)bi][d], xj = bj >= 0 ? vb.x[(size_t)bj][d] : 0.0;
+                vb.load[(size_t)wq][d] += xj - xi;
+                vb.load[(size_t)bq][d] += xi - xj;
+            }
+            part[(size_t)bi] = bq;
+            if (bj >= 0) part[(size_t)bj] = wq;
+        }
+    }
+    return part;
 }
 
 std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, const std::vector<int64_t>& cost_b, int n_parts) {

@@ -85,6 +85,27 @@ std::vector<int64_t> host_instance_cost(const int* ptr, const std::vector<int64_
 // 12 rows + nonzeros the tiers were ignored -- a row of 17..64 nonzeros costs four times a row of 16 -- and the
 // slowest partition still ran 1.3 x the mean.)
 std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, const std::vector<int64_t>& cost_b, int n_parts);
+// Round 4.  The five kernel families of the fused path (forward-16, backward-16, source-16, forward-1, backward-1) have
+// different costs per item and per step, so ONE scalar cost per instance balanced the model and not the measurement: the
+// stamps of round 3 showed whole partitions 20 % under and over the mean (profiles/r03_fused_stamps.txt).  The time of a
+// partition in any of these kernels is a_k * items + b_k * steps + c_k * block rows of the orientation the kernel walks,
+// with kernel-specific a, b, c: a partition that holds an eighth of EACH of these quantities, for both orientations and
+// both geometries (16-channel: 16 base rows / 4 group rows / 1 wave row per item, 4 nonzeros per quad and step; 1-channel:
+// 64 / 16 / 1, 8 nonzeros per lane and step), is balanced for all of them whatever the coefficients are.
+// (a block row in items: the model of rounds 2-3 charged 25 k cycles to each of the 12 wavefronts = 43 items, and the partition
+// that held the Netlib batch's block rows ran 25 % under the mean; the stamps of round 4 fit 10)
+constexpr int FUSED_BLOCK_ROW_ITEMS = 10;
+constexpr int FUSED_LOAD_DIMS = 5;       // {items16, steps16, items1, steps1, block rows} of one orientation, fixed point
+struct InstLoad {
+    int64_t d[FUSED_LOAD_DIMS] = {0, 0, 0, 0, 0};
+};
+std::vector<InstLoad> host_instance_loads(const int* ptr, const std::vector<int64_t>& inst_off);
+// Deterministic.  Largest instance first, each to the partition that keeps the largest normalised load over all 2 x 5
+// quantities lowest; then pairwise moves / swaps while they lower that maximum.
+std::vector<int> host_partition_instances_v(const std::vector<InstLoad>& a, const std::vector<InstLoad>& b, int n_parts);
+// max over partitions and quantities of (load of the partition) / (an n_parts-th of the total): 1.0 = perfectly even
+double host_partition_imbalance(const std::vector<InstLoad>& a, const std::vector<InstLoad>& b, const std::vector<int>& part,
+                                int n_parts);
 // inst_off: [n_inst + 1] offsets of the instances' nodes (rows of this orientation)
 void host_build_fused_orient(const int* ptr, int n, const std::vector<int64_t>& inst_off, const std::vector<int>& inst_part,
                              HostFusedOrient* out);

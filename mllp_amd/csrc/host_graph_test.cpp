@@ -366,6 +366,16 @@ int main(int argc, char** argv) {
                 CHECK(la[q] <= 2 * (sa / FUSED_PARTS + ma) && lb[q] <= 2 * (sb / FUSED_PARTS + mb));
             check_fused(b.csr_ptr.data(), (int)b.M, b.pm, part);
             check_fused(b.csc_ptr.data(), (int)b.N, b.pn, part);
+            // round 4: the partition that the library uses balances items, steps and block rows of both orientations
+            const std::vector<InstLoad> va = host_instance_loads(b.csr_ptr.data(), b.pm), vc = host_instance_loads(b.csc_ptr.data(), b.pn);
+            CHECK((int)va.size() == n_inst && (int)vc.size() == n_inst);
+            const std::vector<int> pv = host_partition_instances_v(va, vc, FUSED_PARTS);
+            CHECK(pv == host_partition_instances_v(va, vc, FUSED_PARTS));
+            for (int k = 0; k < n_inst; ++k) CHECK(pv[k] >= 0 && pv[k] < FUSED_PARTS);
+            // never worse than the scalar rule of rounds 2-3 on the quantities it balances
+            CHECK(host_partition_imbalance(va, vc, pv, FUSED_PARTS) <= host_partition_imbalance(va, vc, part, FUSED_PARTS) + 1e-9);
+            check_fused(b.csr_ptr.data(), (int)b.M, b.pm, pv);
+            check_fused(b.csc_ptr.data(), (int)b.N, b.pn, pv);
         }
     }
     check_stream(rng, 2600, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 4 column blocks, a 1400-entry row

@@ -11,7 +11,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD TA_BUSY_avr" \
            "FETCH_SIZE" "WRITE_SIZE" ; do
   i=$((i+1))
-  if [ $i -gt ${PMC_PASSES:-2} ]; then break; fi
+  if [ $i -gt ${PMC_PASSES:-4} ]; then break; fi
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/$tag/pass$i -- python3 tools/profile_attn_stream.py $n 3 stream $dv > gpurun_out/$tag/pass$i.log 2>&1
   rc=$?; echo "pass$i rc=$rc"; if [ $rc -ne 0 ]; then tail -5 gpurun_out/$tag/pass$i.log; exit $rc; fi
 done

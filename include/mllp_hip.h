@@ -74,7 +74,10 @@ int mllp_graph_create_host(int64_t n_inst, const int64_t* inst_m, const int64_t*
  * whatever order the scatter's atomics produced; mllp_amd/csrc/transpose.hip): the second orientation that
  * mllp_graph_create_device wants, for batches that were generated or loaded on the GPU.  All arrays are caller-owned
  * device memory: d_ptr [n_rows + 1], d_idx / d_val [nnz] (column ids ascending inside a row), outputs d_t_ptr
- * [n_cols + 1], d_t_idx / d_t_val [nnz].  Allocates scratch and synchronises `stream` (not a launch function).    */
+ * [n_cols + 1], d_t_idx / d_t_val [nnz].  Allocates scratch and synchronises `stream` (not a launch function).
+ * The input is checked on the device first: d_ptr must ascend from 0 to nnz and the column ids of a row must be
+ * strictly ascending and smaller than n_cols (no duplicate entries, which the per-column ordering could not keep
+ * apart); anything else returns MLLP_EINVAL and writes nothing.                                                */
 int mllp_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* d_ptr, const int32_t* d_idx,
                               const float* d_val, int32_t* d_t_ptr, int32_t* d_t_idx, float* d_t_val, void* stream);
 

@@ -1662,18 +1662,27 @@ struct TailArgs {
     int n_params;
     float* D[MODEL_CONVS];          // folded weights (the batch's workspace)
     unsigned long long* sync;       // [0] arrivals (cumulative over launches), [1] launches so far
+    unsigned* err;                  // host-mapped word: != 0 once a barrier has timed out (checked by the host at the next call)
 };
-__device__ __forceinline__ void tail_barrier(unsigned long long* cnt, unsigned long long target) {
+// Grid barrier of an ordinary (non-cooperative) launch: 36 workgroups on 256 CUs are co-resident unless something else
+// holds the device.  The spin is bounded so that a workgroup that is never scheduled cannot hang the others; a timeout is
+// NOT silent: the workgroup raises the error word and the kernel skips Adam and the weight folding -- also in
+// the workgroups that arrive late and find the count complete -- and the host refuses the next call.
+__device__ __forceinline__ bool tail_barrier(unsigned long long* cnt, unsigned long long target, unsigned* err) {
+    __shared__ int ok_s;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;      // (bounded: a workgroup that is never scheduled must not hang the others)
+        int spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(8);
+        if (spins >= (1 << 22)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence();
+        ok_s = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
     }
     __syncthreads();
+    return ok_s != 0;
 }
 __global__ __launch_bounds__(RT) void fused_tail_kernel(TailArgs A, int n_conv) {
     const unsigned long long G = gridDim.x, epoch = A.sync[1];
@@ -1681,7 +1690,7 @@ __global__ __launch_bounds__(RT) void fused_tail_kernel(TailArgs A, int n_conv) 
     // (every workgroup reads the optimizer's scalars before the barrier; one of them writes the step count behind it)
     const float step = A.state[0] + 1.0f, lr = A.state[1], b1 = A.state[2], b2 = A.state[3];
     fused_reduce_body(A.R, n_conv);                                         // all workgroups: the partials
-    tail_barrier(A.sync, (epoch + 1) * G);
+    if (!tail_barrier(A.sync, (epoch + 1) * G, A.err)) return;
     // From here on a workgroup works on ITS conv alone: gradients -> Adam on the conv's parameter range -> folded
     // weights; no conv needs another one's result (the never-used gconv3_s2w has zero gradients and zero moments: Adam
     // leaves it where it is, exactly as the separate launch does).
@@ -1811,6 +1820,9 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if (!g->tail_sync) {
         if ((rc = dev_alloc(g, (size_t)2, &g->tail_sync))) return rc;
         MLLP_HIP_TRY(hipMemset(g->tail_sync, 0, 16));
+        MLLP_HIP_TRY(hipHostMalloc((void**)&g->tail_err_host, 64, hipHostMallocMapped));
+        *g->tail_err_host = 0u;
+        MLLP_HIP_TRY(hipHostGetDevicePointer((void**)&g->tail_err_dev, g->tail_err_host, 0));
     }
     if (g->M > 0) {
         hipLaunchKernelGGL(fused_fill_kernel, dim3((unsigned)((g->M + 3) / 4)), dim3(256), 0, 0, (int)g->M, g->perm_c, g->A.ptr,
@@ -2045,6 +2057,10 @@ int fused_backward(const mllp_graph* g, const FusedModel& m, bool premasked, flo
         T.eps = adam->eps;
         T.n_params = adam->n;
         T.sync = g->tail_sync;
+        T.err = g->tail_err_dev;
+        if (g->tail_err_host && *(volatile unsigned*)g->tail_err_host != 0u)
+            return fail(MLLP_EHIP, "the grid barrier of fused_tail_kernel timed out in an earlier step (the device was shared with "
+                                   "other work): parameters and optimizer state since then are invalid; recreate the graph");
         hipLaunchKernelGGL(fused_tail_kernel, dim3(MODEL_CONVS * STAT_TILES + 1), dim3(RT), 0, s, T, MODEL_CONVS);
         return check_launch("fused_tail");
     }

@@ -224,6 +224,7 @@ extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     for (mllp::Orient* o : {&g->A, &g->At})
         for (mllp::Tiled* tl : {&o->tiled, &o->tiled_attn, &o->tiled_bsrc, &o->tiled_scalar, &o->tiled_bdst}) mllp::tiled_free(*tl);
     for (void* p : g->allocs) (void)hipFree(p);
+    if (g->tail_err_host) (void)hipHostFree(g->tail_err_host);
     for (auto& e : g->ev)
         if (e) (void)hipEventDestroy(e);
     if (g->aux) (void)hipStreamDestroy(g->aux);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -83,7 +84,12 @@ extern "C" int mllp_mps_read(const char* path, int normalize, mllp_lp_t** out) {
 
 static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out) {
     using mllp::fail;
-    FILE* fh = std::fopen(path, "r");
+    // (the file handle, the getline buffer and the result are owned by RAII holders: an exception thrown while parsing --
+    // bad_alloc on a huge file -- unwinds through them)
+    struct FileCloser { void operator()(FILE* f) const { if (f) std::fclose(f); } };
+    struct LineBuf { char* p = nullptr; ~LineBuf() { std::free(p); } };
+    std::unique_ptr<FILE, FileCloser> fh_owner(std::fopen(path, "r"));
+    FILE* fh = fh_owner.get();
     if (!fh) return fail(MLLP_EINVAL, std::string("mllp_mps_read: cannot open ") + path);
     std::vector<std::string> rows, cols;
     std::unordered_map<std::string, int> ridx, cidx;
@@ -96,7 +102,8 @@ static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out) {
     std::vector<std::string> range_order;             // first appearance
     std::string sec;
     std::vector<std::string> f;
-    char* line = nullptr;
+    LineBuf lb;
+    char*& line = lb.p;
     size_t cap = 0;
     int lineno = 0, rc = MLLP_OK;
     std::string err;
@@ -159,13 +166,13 @@ static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out) {
             if (rc) break;
         }   // BOUNDS, OBJSENSE, NAME continuation: read and ignored
     }
-    std::free(line);
-    std::fclose(fh);
+    fh_owner.reset();
     if (rc) return fail(rc, std::string("mllp_mps_read: ") + path + ":" + std::to_string(lineno) + ": " + err);
 
     const int64_t m = (int64_t)rows.size();
     int64_t n = (int64_t)cols.size();
-    mllp_lp* lp = new mllp_lp();
+    std::unique_ptr<mllp_lp> lp_owner(new mllp_lp());
+    mllp_lp* lp = lp_owner.get();
     lp->n_struct = n;
     std::vector<double> b((size_t)m, 0.0);
     for (const auto& kv : rhs) {
@@ -223,7 +230,7 @@ static int mps_read_impl(const char* path, int normalize, mllp_lp_t** out) {
     }
     lp->coefs = std::move(c);
     lp->rhs = std::move(b);
-    *out = lp;
+    *out = lp_owner.release();
     return MLLP_OK;
 }
 

@@ -20,6 +20,26 @@ constexpr int TR_T = 256;
 constexpr int TR_WAVE_MAX = 1024;       // entries of a column that one wavefront orders in LDS (8 KB per wavefront)
 constexpr int TR_SCAN = 1024;           // elements per scan block
 
+// input check: the row pointers ascend from 0 to nnz, and inside a row the column ids are strictly ascending
+// and below n_cols -- a duplicate (row, column) would give two entries of a column the same rank in tr_sort_*, an id out
+// of range would send tr_count's atomic outside its array.  bad[0] != 0 afterwards: MLLP_EINVAL, nothing else is launched.
+__global__ void tr_validate(const int* __restrict__ ptr, const int* __restrict__ idx, long long n_rows, long long n_cols,
+                            long long nnz, int* __restrict__ bad) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (long long)gridDim.x * blockDim.x) {
+        const long long b = ptr[r], e = ptr[r + 1];
+        bool ok = b <= e && b >= 0 && e <= nnz && (r > 0 || b == 0) && (r + 1 < n_rows || e == nnz);
+        if (ok) {
+            long long last = -1;
+            for (long long k = b; k < e; ++k) {
+                const long long c = idx[k];
+                ok = ok && c > last && c < n_cols;
+                last = c;
+            }
+        }
+        if (!ok) atomicOr(bad, 1);
+    }
+}
+
 __global__ void tr_count(const int* __restrict__ idx, long long nnz, int* __restrict__ cnt) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (long long)gridDim.x * blockDim.x)
         atomicAdd(&cnt[idx[e]], 1);
@@ -175,6 +195,7 @@ extern "C" int mllp_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t
         return fail(MLLP_EINVAL, "mllp_csr_transpose_device: bad arguments");
     if (nnz >= INT32_MAX || n_rows >= INT32_MAX || n_cols >= INT32_MAX)
         return fail(MLLP_ERANGE, "mllp_csr_transpose_device: sizes exceed int32 indexing");
+    if (n_rows == 0 && nnz != 0) return fail(MLLP_EINVAL, "mllp_csr_transpose_device: nonzeros without rows");
     hipStream_t s = (hipStream_t)stream;
     const long long n1 = n_cols + 1;
     const int n_part = (int)((n1 + TR_SCAN - 1) / TR_SCAN);
@@ -191,6 +212,18 @@ extern "C" int mllp_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t
     auto bail = [&](hipError_t err, const char* what) { cleanup(); return hip_fail(err, what); };
     if ((e = hipMemsetAsync(cnt, 0, (size_t)n1 * 4, s)) != hipSuccess || (e = hipMemsetAsync(n_long, 0, 4, s)) != hipSuccess)
         return bail(e, "transpose: memset");
+    {   // (n_long doubles as the flag of the input check: read back before anything indexes with the column ids)
+        hipLaunchKernelGGL(tr_validate, dim3(4096), dim3(TR_T), 0, s, d_ptr, d_idx, (long long)n_rows, (long long)n_cols,
+                           (long long)nnz, n_long);
+        int h_bad = 0;
+        if ((e = hipMemcpyAsync(&h_bad, n_long, 4, hipMemcpyDeviceToHost, s)) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess)
+            return bail(e, "transpose: input check");
+        if (h_bad) {
+            cleanup();
+            return fail(MLLP_EINVAL, "mllp_csr_transpose_device: the row pointers must ascend from 0 to nnz and the column ids of a "
+                                     "row must be strictly ascending and smaller than n_cols (no duplicate entries)");
+        }
+    }
     if (nnz > 0) hipLaunchKernelGGL(tr_count, dim3(4096), dim3(TR_T), 0, s, d_idx, (long long)nnz, cnt);
     hipLaunchKernelGGL(tr_scan_sums, dim3(n_part), dim3(TR_T), 0, s, cnt, n1, part);
     hipLaunchKernelGGL(tr_scan_parts, dim3(1), dim3(1024), 0, s, part, n_part);

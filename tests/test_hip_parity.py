@@ -1160,6 +1160,18 @@ def test_device_transposition_equals_stable_sort():
             assert torch.equal(a, b), (what, m, n)
         again = lib_transpose(p, i, v, m, n)                               # whatever order the atomics took this time
         assert all(torch.equal(a, b) for a, b in zip(again, got))
+    # input the per-column ordering could not keep apart is refused before anything is written (MLLP_EINVAL)
+    def dev(a):
+        return torch.tensor(a, dtype=torch.int32, device="cuda")
+    bad = {"duplicate entry": ([0, 3, 5], [1, 4, 4, 0, 2]), "descending ids": ([0, 3, 5], [1, 5, 4, 0, 2]),
+           "id out of range": ([0, 3, 5], [1, 4, 6, 0, 2]), "negative id": ([0, 3, 5], [-1, 4, 5, 0, 2]),
+           "row pointers descend": ([0, 4, 3, 5], [0, 1, 2, 3, 4]), "row pointers do not end at nnz": ([0, 3, 4], [1, 4, 5, 0, 2])}
+    for what, (p, i) in bad.items():
+        p, i = dev(p), dev(i)
+        with pytest.raises(_lib.MllpError, match="ascending"):
+            lib_transpose(p, i, torch.ones(5, device="cuda"), p.numel() - 1, 6)
+    ok = lib_transpose(dev([0, 3, 5]), dev([1, 4, 5, 0, 2]), torch.ones(5, device="cuda"), 2, 6)   # and the library still works
+    assert ok[0].tolist() == [0, 1, 2, 3, 3, 4, 5] and ok[1].tolist() == [1, 0, 1, 0, 0]
     # the two ways to build a batch give the same graph arrays
     a = synthetic_batch(n_inst=2, m=300, n=500, mean_row_nnz=10.0, seed=9, chunk=1)
     for k in range(3, 6):

@@ -422,20 +422,54 @@ def main():
                         sb.drop_stream_copy(dst_is_var if g_ != 2 else not dst_is_var, g_)
             del ws, dh, h_ref, ref_b
         del Hm
-        # layer-1 (one channel) conv: generic sweeps, then the LDS-tiled lane-per-row kernels (variant 3)
-        cp1 = params0[144:288].contiguous()
-        x1s, x1d = torch.randn(sb.N, device="cuda"), torch.randn(sb.M, device="cuda")
-        ws1 = sb.tconv_workspace(False, 1)
-        b_f1 = sb.nnz * 8 + 4 * (sb.M + 1) + sb.N * 4 + sb.M * (4 + 64 + 4 + 16)
-        ms_1g = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
-        kernels.append({"kernel": "tconv_fwd1 generic (lane per nonzero, 4-byte gathers from L2), dst=constraints",
-                        "ms": ms_1g, "alg_bytes": b_f1, "GBps": b_f1 / ms_1g / 1e6, "frac": b_f1 / ms_1g / 1e6 / HBM_PEAK_GBS})
-        if sb.enable_tiled(False, variant=3):
-            ms_1t = timed(lambda: sb.tconv_fwd(False, 1, cp1, x1s, x1d, ws1), 10, warm=3)
-            kernels.append({"kernel": "tconv_fwd1 LDS-tiled (scalar_tiled_kernel, lane per row), dst=constraints",
-                            "ms": ms_1t, "alg_bytes": b_f1, "GBps": b_f1 / ms_1t / 1e6,
-                            "frac": b_f1 / ms_1t / 1e6 / HBM_PEAK_GBS})
-        del ws1, x1s, x1d
+        # layer-1 (one channel) conv, both orientations: generic sweeps, the LDS-tiled lane-per-row kernel (variant 3), the
+        # lane-per-row STREAMED copy (geometry 4, lane_stream.hip: the one the training step uses)
+        for dst_is_var, off1 in ((False, 144), (True, 0)):
+            label = "dst=variables" if dst_is_var else "dst=constraints"
+            nd, ns = (sb.N, sb.M) if dst_is_var else (sb.M, sb.N)
+            cp1 = params0[off1:off1 + 144].contiguous()
+            x1s, x1d = torch.randn(ns, device="cuda"), torch.randn(nd, device="cuda")
+            dh1 = torch.randn(nd, 16, device="cuda")
+            ws1 = sb.tconv_workspace(dst_is_var, 1)
+            b_f1 = sb.nnz * 8 + 4 * (nd + 1) + ns * 4 + nd * (4 + 64 + 4 + 16)       # CSR bytes: what the reference's layout costs
+            b_b1 = sb.nnz * 8 + 4 * (nd + 1) + ns * 4 + nd * (32 + 12 + 64 + 64)
+            h1_ref = pg1_ref = None
+            keep1 = torch.ones(144, dtype=torch.bool, device="cuda")
+            keep1[16:32] = False                                                      # lin_key.bias cancels in the softmax
+            for kind in ("generic", "LDS-tiled", "streamed"):
+                if kind == "LDS-tiled" and not sb.enable_tiled(dst_is_var, variant=3):
+                    continue
+                if kind == "streamed":
+                    sb.build_stream_copy(dst_is_var, 4)
+                ms_f1 = timed(lambda: sb.tconv_fwd(dst_is_var, 1, cp1, x1s, x1d, ws1), 10, warm=3)
+                h1 = sb.tconv_fwd(dst_is_var, 1, cp1, x1s, x1d, ws1)
+                hh = h1 if h1_ref is None else h1_ref          # every backward is masked with the generic forward's output
+                ms_b1 = timed(lambda: sb.tconv_bwd(dst_is_var, 1, cp1, x1s, x1d, hh, ws1, dh1), 10, warm=3)
+                pg1 = sb.tconv_bwd(dst_is_var, 1, cp1, x1s, x1d, hh, ws1, dh1)[0]
+                how = {"generic": "lane per nonzero, 4-byte gathers from L2",
+                       "LDS-tiled": "scalar_tiled_kernel, lane per row, 1024-column blocks",
+                       "streamed": "lane1_kernel, lane per row, entries HBM -> registers at 6 B / nonzero, the instance's x in LDS"}[kind]
+                lf = {"kernel": f"tconv_fwd1 {kind} ({how}), {label}", "ms": ms_f1, "alg_bytes": b_f1,
+                      "GBps": b_f1 / ms_f1 / 1e6, "frac": b_f1 / ms_f1 / 1e6 / HBM_PEAK_GBS}
+                lb = {"kernel": f"tconv_bwd1 {kind} (bwd_pre + destination-major sweep + parameter statistics + finalize), {label}",
+                      "ms": ms_b1, "alg_bytes": b_b1, "GBps": b_b1 / ms_b1 / 1e6, "frac": b_b1 / ms_b1 / 1e6 / HBM_PEAK_GBS}
+                if h1_ref is None:
+                    h1_ref, pg1_ref = h1.clone(), pg1.clone()
+                else:
+                    d_h = float((h1 - h1_ref).abs().max() / h1_ref.abs().max())
+                    d_g = float((pg1[keep1] - pg1_ref[keep1]).abs().max() / pg1_ref[keep1].abs().max())
+                    lf["max_rel_diff_vs_generic"] = d_h
+                    lb["max_rel_diff_vs_generic"] = d_g
+                    if kind == "streamed" and not d_h <= 2e-6:
+                        gate_fail.append(f"tconv_fwd1 streamed {label}: {d_h:.3e} > 2e-6")
+                    if kind == "streamed" and not d_g <= 5e-6:
+                        gate_fail.append(f"tconv_bwd1 streamed {label}: {d_g:.3e} > 5e-6")
+                kernels += [lf, lb]
+                if kind == "LDS-tiled":
+                    sb.disable_tiled(dst_is_var, variant=3)
+                if kind == "streamed":
+                    sb.drop_stream_copy(dst_is_var, 4)
+            del ws1, x1s, x1d, dh1, h1_ref, pg1_ref
         out["roofline"] = {"bound": "hbm", "kernel": "spmm_stream_kernel (plain CSR SpMM, Y = A*H, C=16, fp32, streamed copy: "
                                                      "entries HBM -> registers, H double-buffered in LDS by LDS-DMA)",
                            "workload": f"synthetic BASELINE.json configs[3]: {sb.n_inst} x (m=10000, n=20000), "
@@ -449,9 +483,8 @@ def main():
                            "kernels": kernels}
         del Hn
         # full training step on the synthetic batch with the copies LPTrainer attaches by itself (streamed copies of the
-        # 16-channel sweeps, LDS-tiled variant 3 for layer 1); its logits against those of the generic sweeps at the same full
+        # 16-channel sweeps, lane-per-row copies for layer 1); its logits against those of the generic sweeps at the same full
         # size (taken above, before any copy was attached)
-        sb.disable_tiled(False, variant=3)
         sb.tiled_build_s = 0.0
         sb.stream_build_s = 0.0
         tr = LPTrainer(params0, lr=1e-3, use_hip_graph=False, global_instances=sb.n_inst * world)
@@ -478,9 +511,8 @@ def main():
                             "graph_build": "CSR -> CSC (one stable device sort) + row tiers, mllp_graph_create_device",
                             "tiled_build_s": getattr(sb, "tiled_build_s", None),
                             "stream_build_s": getattr(sb, "stream_build_s", None),
-                            "copies": "6 streamed copies of the 16-channel attention sweeps (geometries 1-3 x 2 orientations, "
-                                      "mllp_graph_build_stream_copy) + 2 LDS-tiled copies of the layer-1 sweeps (variant 3, "
-                                      "mllp_graph_build_tiled), HIP builders",
+                            "copies": "8 streamed copies (mllp_graph_build_stream_copy, device builders): geometries 1-3 of the "
+                                      "16-channel attention sweeps + the lane-per-row copy (4) of the layer-1 sweeps, x 2 orientations",
                             "logits_max_rel_diff_streamed_vs_generic": logits_diff,
                             "logits_max_rel_diff_tiled_vs_generic": logits_diff,
                             "parity_gates": {"failed": list(gate_fail), "limits": "SpMM / conv forward 2e-6, conv backward and "

@@ -221,6 +221,7 @@ extern "C" int mllp_graph_destroy(mllp_graph_t* g) {
     if (!g) return MLLP_OK;
     for (mllp::Orient* o : {&g->A, &g->At})
         for (mllp::StreamCopy* sc : {&o->stream, &o->stream_attn, &o->stream_bsrc, &o->stream_bdst}) mllp::stream_copy_free(*sc);
+    for (mllp::Orient* o : {&g->A, &g->At}) mllp::lane_copy_free(o->lane1);
     for (mllp::Orient* o : {&g->A, &g->At})
         for (mllp::Tiled* tl : {&o->tiled, &o->tiled_attn, &o->tiled_bsrc, &o->tiled_scalar, &o->tiled_bdst}) mllp::tiled_free(*tl);
     for (void* p : g->allocs) (void)hipFree(p);

@@ -57,7 +57,23 @@ struct StreamCopy {
     double build_seconds = 0.0;
 };
 
+// lane-per-row streamed copy of one orientation for the layer-1 sweeps (lane_layout.h, lane_stream.hip)
+struct LaneCopy {
+    int n_tiles = 0, n_tb = 0;
+    int64_t n_groups = 0;       // groups of 4 steps, without the padding groups at the end
+    int64_t nnz = 0;
+    int* tile_row = nullptr;    // [n_tiles + 1]
+    int* tile_blk = nullptr;    // [n_tiles + 1]
+    int* tile_col = nullptr;    // [n_tiles][2]
+    int* rows = nullptr;        // [n_tiles][L1_R]
+    int* whdr = nullptr;        // [n_tb][L1_NW][2]
+    unsigned* offs = nullptr;   // [(n_groups + L1_PADG) * 64 * 2]
+    float* vals = nullptr;      // [(n_groups + L1_PADG) * 64 * 4]
+    double build_seconds = 0.0;
+};
+
 struct Orient {
+    LaneCopy lane1;     // geometry 4: layer-1 sweeps, destination-major (lane_stream.hip); takes precedence over tiled_scalar
     StreamCopy stream;  // plain SpMM on the streamed copy (stream_spmm.hip); takes precedence over `tiled`
     StreamCopy stream_attn;  // geometry 1: attention forward (stream_attn.hip); takes precedence over tiled_attn
     StreamCopy stream_bdst;  // geometry 3: destination-major attention backward; over tiled_bdst
@@ -207,6 +223,12 @@ int launch_fwd16_stream(const StreamCopy& sc, int n_dst, int n_src, const float*
                         const float* x_src, const float* x_dst, float* h_out, hipStream_t s);      // stream_attn.hip
 int launch_bwddst16_stream(const StreamCopy& sc, int n_dst, int n_src, const ConvWs& w, const float* x_src, const float* g,
                            float* dx_dst, int accumulate, hipStream_t s);
+struct ConvWs;
+int launch_fwd1_lane(const LaneCopy& lc, int n_dst, int n_src, const float* conv_params, const ConvWs& w, const float* x_src,
+                     const float* x_dst, float* h_out, hipStream_t s);                              // lane_stream.hip
+int launch_bwddst1_lane(const LaneCopy& lc, int n_dst, int n_src, const ConvWs& w, const float* x_src, hipStream_t s);
+int build_lane_copy(const Orient& o, int64_t nnz, const std::vector<int64_t>& seg, LaneCopy& lc, hipStream_t s);
+void lane_copy_free(LaneCopy& lc);
 int launch_bwdsrc16_stream(const StreamCopy& sc, int n_rows, int n_cols, const float* rec, const float* x_rows, float* dx,
                            int accumulate, hipStream_t s);
 int launch_spmm_tiled(const Tiled& tl, int n_dst, int n_src, const float* H, float* Y, hipStream_t s);

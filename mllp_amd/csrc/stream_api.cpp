@@ -5,6 +5,7 @@
 
 #include "host_stream.h"
 #include "internal.h"
+#include "lane_layout.h"
 #include "stream_layout.h"
 
 namespace mllp {
@@ -76,6 +77,22 @@ StreamCopy* copy_slot(mllp_graph_t* g, int transpose, int geom) {
 extern "C" int mllp_graph_build_stream_copy(mllp_graph_t* g, int transpose, int geom, int where, void* stream) {
     REQUIRE(g, "null graph");
     REQUIRE(where == 0 || where == 1, "where must be 0 (device builder) or 1 (host reference builder)");
+    if (geom == STREAM_GEOM_LANE1) {         // the lane-per-row copy of the layer-1 sweeps (lane_layout.h): device builder only
+        REQUIRE(where == 0, "geometry 4 has no host builder");
+        Orient& o = transpose ? g->At : g->A;
+        lane_copy_free(o.lane1);
+        if (o.n_dst == 0) return MLLP_OK;
+        const auto t0 = std::chrono::steady_clock::now();
+        LaneCopy lc;
+        const int rc = build_lane_copy(o, g->nnz, transpose ? g->h_inst_ptr_n : g->h_inst_ptr_m, lc, (hipStream_t)stream);
+        if (rc) {
+            lane_copy_free(lc);
+            return rc;
+        }
+        lc.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        o.lane1 = lc;
+        return MLLP_OK;
+    }
     GeomInfo gi;
     REQUIRE(geom_info(geom, &gi), "geom must be 0 (plain SpMM), 1 (attention forward), 2 (source-major backward) or 3 (destination-major backward)");
     Orient& o = transpose ? g->At : g->A;
@@ -99,6 +116,10 @@ extern "C" int mllp_graph_build_stream_copy(mllp_graph_t* g, int transpose, int 
 
 extern "C" int mllp_graph_drop_stream_copy(mllp_graph_t* g, int transpose, int geom) {
     REQUIRE(g, "null graph");
+    if (geom == STREAM_GEOM_LANE1) {
+        lane_copy_free((transpose ? g->At : g->A).lane1);
+        return MLLP_OK;
+    }
     StreamCopy* sc = copy_slot(g, transpose, geom);
     REQUIRE(sc, "unknown geometry");
     stream_copy_free(*sc);
@@ -107,6 +128,20 @@ extern "C" int mllp_graph_drop_stream_copy(mllp_graph_t* g, int transpose, int g
 
 extern "C" int mllp_graph_stream_copy_info(const mllp_graph_t* g, int transpose, int geom, int64_t info[8]) {
     REQUIRE(g && info, "null argument");
+    if (geom == STREAM_GEOM_LANE1) {
+        const LaneCopy& lc = (transpose ? g->At : g->A).lane1;
+        info[0] = lc.n_tiles;
+        info[1] = lc.n_tb;
+        info[2] = lc.n_groups;
+        info[3] = lc.n_groups * 64 * L1_GS;                     // entry slots of the stream, padding included
+        info[4] = lc.n_tiles ? ((int64_t)lc.n_tiles + 1) * 8 + (int64_t)lc.n_tiles * (8 + L1_R * 4) + (int64_t)lc.n_tb * L1_NW * 8 +
+                                   (lc.n_groups + L1_PADG) * 64 * 24
+                             : 0;
+        info[5] = (int64_t)(lc.build_seconds * 1e6);
+        info[6] = L1_R | (int64_t)1 << 16 | (int64_t)4 << 24;   // rows per tile, one row per lane, 4-byte items
+        info[7] = (int64_t)L1_CB | (int64_t)L1_NW << 16 | (int64_t)L1_PADG << 24;
+        return MLLP_OK;
+    }
     GeomInfo gi;
     REQUIRE(geom_info(geom, &gi), "unknown geometry");
     const StreamCopy& sc = *copy_slot(const_cast<mllp_graph_t*>(g), transpose, geom);
@@ -126,6 +161,26 @@ extern "C" int mllp_graph_stream_copy_info(const mllp_graph_t* g, int transpose,
 extern "C" int mllp_graph_export_stream_copy(const mllp_graph_t* g, int transpose, int geom, int which, void* host_dst,
                                              int64_t capacity_bytes) {
     REQUIRE(g && host_dst, "null argument");
+    if (geom == STREAM_GEOM_LANE1) {
+        const LaneCopy& lc = (transpose ? g->At : g->A).lane1;
+        REQUIRE(lc.n_tiles > 0, "no lane-per-row copy of this orientation (mllp_graph_build_stream_copy, geometry 4)");
+        const void* src = nullptr;
+        int64_t bytes = 0;
+        switch (which) {
+            case 0: src = lc.tile_blk; bytes = ((int64_t)lc.n_tiles + 1) * 4; break;
+            case 1: src = lc.tile_col; bytes = (int64_t)lc.n_tiles * 8; break;
+            case 2: src = lc.rows; bytes = (int64_t)lc.n_tiles * L1_R * 4; break;
+            case 3: src = lc.offs; bytes = (lc.n_groups + L1_PADG) * 64 * 8; break;
+            case 4: src = lc.tile_row; bytes = ((int64_t)lc.n_tiles + 1) * 4; break;
+            case 5: src = lc.whdr; bytes = (int64_t)lc.n_tb * L1_NW * 8; break;
+            case 6: src = lc.vals; bytes = (lc.n_groups + L1_PADG) * 64 * 16; break;
+            default: return fail(MLLP_EINVAL, "mllp_graph_export_stream_copy: geometry 4 has arrays 0 (tile_blk), 1 (tile_col), 2 (rows), 3 (offs), 4 (tile_row), 5 (whdr), 6 (vals)");
+        }
+        REQUIRE(capacity_bytes >= bytes, "destination too small");
+        MLLP_HIP_TRY(hipDeviceSynchronize());
+        if (bytes > 0) MLLP_HIP_TRY(hipMemcpy(host_dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+        return MLLP_OK;
+    }
     GeomInfo gi;
     REQUIRE(geom_info(geom, &gi), "unknown geometry");
     const StreamCopy& sc = *copy_slot(const_cast<mllp_graph_t*>(g), transpose, geom);

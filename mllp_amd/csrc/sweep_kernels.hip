@@ -708,6 +708,7 @@ int launch_attn_fwd(const Orient& o, int cin, const float* conv_params, const Co
     if (cin == 16 && o.tiled_attn.n_tiles > 0)
         return launch_fwd16_tiled(o.tiled_attn, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     if (cin == 16) return launch_sweep<Fwd16Op, 4, 4>(o, a, scratch, s, "attn_fwd16");
+    if (o.lane1.n_tiles > 0) return launch_fwd1_lane(o.lane1, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     if (o.tiled_scalar.n_tiles > 0)
         return launch_fwd1_tiled(o.tiled_scalar, o.n_dst, o.n_src, conv_params, w, x_src, x_dst, h_out, s);
     return launch_sweep<Fwd1Op, 2, 2>(o, a, scratch, s, "attn_fwd1");
@@ -725,6 +726,7 @@ int launch_attn_bwd_dst(const Orient& o, int cin, const float* conv_params, cons
         return launch_bwddst16_tiled(o.tiled_bdst, o.n_dst, o.n_src, w, x_src, g, dx_dst, accumulate, s);
     if (cin == 16) return launch_sweep<BwdDst16Op, 4, 4>(o, a, scratch, s, "attn_bwd_dst16");
     a.dx_dst = nullptr;
+    if (o.lane1.n_tiles > 0) return launch_bwddst1_lane(o.lane1, o.n_dst, o.n_src, w, x_src, s);
     if (o.tiled_scalar.n_tiles > 0) return launch_bwddst1_tiled(o.tiled_scalar, o.n_dst, o.n_src, w, x_src, s);
     return launch_sweep<BwdDst1Op, 2, 2>(o, a, scratch, s, "attn_bwd_dst1");
 }

@@ -401,7 +401,8 @@ class LPBatch:
 
     def build_stream_copy(self, transpose=False, geom=1, where="device"):
         """Build the streamed copy of geometry `geom` (0 plain SpMM, 1 attention forward, 2 source-major backward,
-        3 destination-major backward) of A (or A^T); the sweeps use it when present.  Returns `stream_copy_info`."""
+        3 destination-major backward, 4 lane-per-row copy of the layer-1 sweeps) of A (or A^T); the sweeps use it when
+        present.  Returns `stream_copy_info`."""
         t0 = time.perf_counter()
         _lib.check(_lib.lib().mllp_graph_build_stream_copy(self._h, int(transpose), int(geom),
                                                            {"device": 0, "host": 1}[where], _lib.current_stream()))
@@ -425,6 +426,20 @@ class LPBatch:
         int32 arrays (tests)."""
         i = self.stream_copy_info(transpose, geom)
         nw = i["wavefronts"]
+        if geom == 4:
+            # lane_layout.h: (tile_blk, tile_col [n_tiles, 2], rows [n_tiles, R], offs [groups + padding, 64, 2] uint32,
+            #                 tile_row, whdr [n_tb * nw, 2], vals [groups + padding, 64, 4] float32)
+            ng = i["n_groups"] + i["pad_groups"]
+            specs = [((i["n_tiles"] + 1,), np.int32), ((i["n_tiles"], 2), np.int32), ((i["n_tiles"], i["row_slots"]), np.int32),
+                     ((ng, 64, 2), np.uint32), ((i["n_tiles"] + 1,), np.int32), ((i["n_tb"] * nw, 2), np.int32),
+                     ((ng, 64, 4), np.float32)]
+            out = []
+            for which, (shp, dt) in enumerate(specs):
+                a = np.empty(shp, dtype=dt)
+                _lib.check(_lib.lib().mllp_graph_export_stream_copy(self._h, int(transpose), 4, which,
+                                                                    a.ctypes.data_as(c_void_p), a.nbytes))
+                out.append(a)
+            return tuple(out)
         shapes = [(i["n_tiles"] + 1,), (i["n_tb"],), (i["n_tb"], nw, 16, 4), (i["n_groups"] + i["pad_groups"], 64, 3),
                   (i["n_tiles"] + 1,), (i["n_tb"], nw, 4)]
         out = []
@@ -436,8 +451,9 @@ class LPBatch:
         return tuple(out)
 
     def enable_stream_step(self):
-        """The streamed copies that the TRAINING STEP's 16-channel attention sweeps use, both orientations: forward (1),
-        source-major backward (2), destination-major backward (3).  Returns {(transpose, geom): info}."""
+        """The streamed copies that the TRAINING STEP's attention sweeps use, both orientations: 16-channel forward (1),
+        source-major backward (2), destination-major backward (3), and the lane-per-row copy of the layer-1 sweeps (4).
+        Returns {(transpose, geom): info}."""
         return {(tr, g): self.build_stream_copy(tr, g) for tr in (False, True) for g in self.STREAM_STEP_GEOMS}
 
     def disable_stream_step(self):
@@ -445,7 +461,7 @@ class LPBatch:
             for g in self.STREAM_STEP_GEOMS:
                 self.drop_stream_copy(tr, g)
 
-    STREAM_STEP_GEOMS = (1, 2, 3)
+    STREAM_STEP_GEOMS = (1, 2, 3, 4)
 
     def enable_tiled_all(self):
         """Attach every LDS-tiled copy (variants 0-4, both orientations): the throughput configuration for batches of

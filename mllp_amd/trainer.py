@@ -107,7 +107,7 @@ class LPTrainer:
 
     # "auto": batches of at least this many nonzeros get the re-blocked copies of the attention sweeps, both orientations
     # (the throughput regime of the library's row tiers starts at the same size): the STREAMED copies for the 16-channel
-    # sweeps (round 4, LPBatch.enable_stream_step) and the LDS-tiled variant 3 for the 1-channel sweeps of layer 1; with
+    # sweeps and the lane-per-row copies for the 1-channel sweeps of layer 1 (round 4, LPBatch.enable_stream_step); with
     # `stream_copies=False` all sweeps run on LDS-tiled copies (round 2-3, LPBatch.enable_tiled_step); smaller batches run
     # the fused latency-regime kernels
     TILED_NNZ_MIN = 32 << 20
@@ -132,14 +132,11 @@ class LPTrainer:
             dev = self.params.device
             graph = (batch.nnz <= self.GRAPH_NNZ_LIMIT) if self.use_graph == "auto" else bool(self.use_graph)
             want_tiled = (batch.nnz >= self.TILED_NNZ_MIN) if self.tiled_copies == "auto" else bool(self.tiled_copies)
-            if want_tiled and not getattr(batch, "_tiled", None):
-                if self.stream_copies:
-                    if not getattr(batch, "_streams", None):
-                        batch._streams = batch.enable_stream_step()
-                    for tr in (False, True):
-                        batch.enable_tiled(tr, variant=3)
-                else:
-                    batch.enable_tiled_step()
+            if want_tiled and self.stream_copies:
+                if not getattr(batch, "_streams", None):
+                    batch._streams = batch.enable_stream_step()
+            elif want_tiled and not getattr(batch, "_tiled", None):
+                batch.enable_tiled_step()
             p = dict(batch=batch, logits=torch.empty(batch.N, device=dev), loss=torch.zeros(1, device=dev),
                      grads=torch.zeros(NUM_PARAMS, device=dev), metrics=torch.zeros(batch.n_inst, 2, device=dev),
                      g_fwd=None, g_opt=None, warm=0, graph=graph)

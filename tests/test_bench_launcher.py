@@ -71,7 +71,7 @@ def test_bench_json_contract_on_the_gpu():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
     k0 = rf["kernels"][0]
     assert abs(k0["GBps"] - k0["alg_bytes"] / k0["ms"] / 1e6) < 1e-6 * k0["GBps"] and k0["max_rel_diff_vs_generic"] < 2e-6
-    assert d["synthetic"]["logits_max_rel_diff_streamed_vs_generic"] < 5e-6 and d["synthetic"]["tiled_build_s"] > 0
+    assert d["synthetic"]["logits_max_rel_diff_streamed_vs_generic"] < 5e-6
     assert d["synthetic"]["stream_build_s"] > 0 and d["synthetic"]["parity_gates"]["failed"] == [] and d["parity_gate_failures"] == []
     # both orientations of the attention conv, forward and backward, generic / LDS-tiled / streamed, with their parity figures
     names = [k["kernel"] for k in rf["kernels"]]
@@ -79,7 +79,13 @@ def test_bench_json_contract_on_the_gpu():
         for what in ("tconv_fwd16 generic", "tconv_bwd16 generic", "tconv_fwd16 LDS-tiled", "tconv_bwd16 LDS-tiled",
                      "tconv_fwd16 streamed", "tconv_bwd16 streamed"):
             assert any(n.startswith(what) and n.endswith(label) for n in names), (what, label)
+        for what in ("tconv_fwd1 generic", "tconv_fwd1 LDS-tiled", "tconv_fwd1 streamed", "tconv_bwd1 streamed"):
+            assert any(n.startswith(what) and n.endswith(label) for n in names), (what, label)
     for k in rf["kernels"]:
+        if k["kernel"].startswith("tconv_fwd1 streamed"):
+            assert k["max_rel_diff_vs_generic"] < 2e-6 and 0.05 < k["frac"] < 1.0
+        if k["kernel"].startswith("tconv_bwd1 streamed"):
+            assert k["max_rel_diff_vs_generic"] < 5e-6
         if k["kernel"].startswith("tconv_fwd16 streamed"):
             assert k["max_rel_diff_vs_generic"] < 2e-6 and 0.05 < k["frac"] < 1.0
         if k["kernel"].startswith("tconv_bwd16 streamed"):

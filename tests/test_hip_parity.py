@@ -671,8 +671,8 @@ def test_tiled_copies_edge_cases(LPBatch, weights):
 
 def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
     """LPTrainer(tiled_copies=True) attaches the re-blocked copies of the training step on first use -- the streamed copies
-    of the 16-channel attention sweeps (round 4: geometries 1-3) and the LDS-tiled variant 3 of the layer-1 sweeps; with
-    stream_copies=False the LDS-tiled variants 1-4 of rounds 2-3; the plain SpMM's copies are not part of the step; the
+    of the 16-channel attention sweeps (round 4: geometries 1-3) and the lane-per-row copies (geometry 4) of the layer-1
+    sweeps; with stream_copies=False the LDS-tiled variants 1-4 of rounds 2-3; the plain SpMM's copies are not part of the step; the
     `auto` policy does the same for batches of >= 32 M nonzeros -- and trains like the generic path: losses of three Adam
     steps agree."""
     from mllp_amd.graph import synthetic_batch
@@ -686,11 +686,11 @@ def test_trainer_attaches_tiled_copies_and_matches_generic(LPBatch, weights):
         for _ in range(3):
             loss, _ = tr.step(sb)
             out.append(float(loss[0]))
-        assert bool(getattr(sb, "_tiled", None)) == bool(mode)
+        assert bool(getattr(sb, "_tiled", None)) == (mode == "tiled")
         if mode is True:
-            assert sorted(sb._tiled) == [(False, 3), (True, 3)] and sb.tiled_build_s > 0 and sb.stream_build_s > 0
-            assert sorted(sb._streams) == [(tr_, g_) for tr_ in (False, True) for g_ in (1, 2, 3)]
-            assert all(sb.stream_copy_info(tr_, g_)["n_tiles"] > 0 for tr_ in (False, True) for g_ in (1, 2, 3))
+            assert sb.stream_build_s > 0
+            assert sorted(sb._streams) == [(tr_, g_) for tr_ in (False, True) for g_ in (1, 2, 3, 4)]
+            assert all(sb.stream_copy_info(tr_, g_)["n_tiles"] > 0 for tr_ in (False, True) for g_ in (1, 2, 3, 4))
         if mode == "tiled":
             assert sorted(sb._tiled) == [(tr_, v) for tr_ in (False, True) for v in (1, 2, 3, 4)]
             assert sb.tiled_build_s > 0 and not getattr(sb, "_streams", None)
@@ -721,7 +721,7 @@ def test_throughput_regime_32M_nonzeros(LPBatch, weights):
     close(Ya.cpu().numpy(), A @ Hn.double().cpu().numpy(), RTOL_ACT, "generic A H vs scipy at 34 M nnz")
     tr = LPTrainer(flat_gpu, lr=1e-3, tiled_copies="auto")
     loss1, logits1 = tr.step(sb)                                       # attaches the copies, then one fused step
-    assert sorted(sb._tiled) == [(False, 3), (True, 3)] and sorted(sb._streams) == [(t_, g_) for t_ in (False, True) for g_ in (1, 2, 3)]
+    assert not getattr(sb, "_tiled", None) and sorted(sb._streams) == [(t_, g_) for t_ in (False, True) for g_ in (1, 2, 3, 4)]
     close(logits1.cpu().numpy(), za.cpu().numpy(), RTOL_ACT, "trainer logits (tiled) vs generic")
     close(loss1.cpu().numpy(), la.cpu().numpy(), RTOL_ACT, "trainer loss (tiled) vs generic")
     assert sb.build_spmm_copy(False)["n_tiles"] > 0 and sb.build_spmm_copy(True)["n_tiles"] > 0

@@ -320,14 +320,18 @@ int mllp_lp_free(mllp_lp_t* lp);
  * linear_program_experiment.py:81-114): three TransformerConv layers (2 -> F, F -> F, and the same F -> F layer
  * again) + Linear(F, 1) on the COMPLETE directed graph over the N = n + 1 nodes of one instance, edge attribute =
  * cosine similarity (build_graph_from_Q_sets, :119-130).  Dense attention with a scalar edge bias:
- *   d_cos    [N, N]  cosine matrix, row = target node, column = source node (the diagonal is ignored: no self loops)
+ *   d_cos    [N, N]  cosine matrix, row = target node, column = source node; SYMMETRIC (the kernels read either triangle);
+ *                    the diagonal is ignored: no self loops
  *   d_x      [N, 2]  node features {coef, |Q row|}
  *   d_params flat fp32 in PyG state_dict order: gconv1, gconv2, gconv3 (each lin_key {W [F,C], b [F]}, lin_query,
  *            lin_value, lin_edge {W [F,1]}, lin_skip {W, b}; C = 2 for gconv1, F otherwise), fc {W [1,F], b [1]}
  *            (mllp_angle_num_params floats; gconv3 is never called by the reference's forward: its gradient is 0)
  *   d_ws     mllp_angle_workspace_floats floats, kept between forward and backward
  *   forward : d_logits [N - 1] = fc(h)[:-1]            backward: d_dlogits [N - 1] -> d_grads (layout of d_params)
- * The N x N x F products are rocBLAS sgemm calls (fp32), everything else hand-written kernels; N <= 46340.   */
+ * Hand-written kernels on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): flash-attention-style forward / backward
+ * sweeps that keep no N x N matrix in HBM (the backward recomputes the weights from the saved row max / row sum) and one
+ * strided GEMM for the projections and their gradients; no BLAS library is linked or loaded.  feat_dim must be 16, 32,
+ * 64, 128 or 256 (MLLP_EINVAL otherwise); N <= 46340; the workspace is O(N * feat_dim * ranges), ranges <= 32.       */
 int mllp_angle_num_params(int feat_dim, int64_t* out);
 int mllp_angle_workspace_floats(int64_t n_nodes, int feat_dim, int64_t* out);
 int mllp_angle_forward(int64_t n_nodes, int feat_dim, const float* d_cos, const float* d_x, const float* d_params,

@@ -11,7 +11,8 @@ Reference surface mirrored here (same names, arguments and outputs):
 The reference builds N (N - 1) PyG edges with one Python call of `cosine_similarity` per edge and runs three
 TransformerConv layers over them.  On a complete graph that is dense attention with a scalar edge bias, so the graph is
 kept as the dense [N, N] cosine matrix on the device and the model runs in libmllp_hip.so (mllp_amd/csrc/angle.hip:
-rocBLAS GEMMs + hand-written row kernels, hand-derived backward).  There is no CPU path.
+flash-attention-style kernels and GEMMs on the fp32 matrix cores, hand-derived backward that recomputes the attention
+weights; no N x N intermediate, no BLAS library).  feat_dim must be 16, 32, 64, 128 or 256.  There is no CPU path.
 """
 import ctypes
 from ctypes import c_int64
@@ -43,7 +44,8 @@ def cosine_matrix(Q):
     nrm = np.linalg.norm(Q, axis=1)
     ok = nrm > 1e-6
     Qn = np.where(ok[:, None], Q / np.where(ok, nrm, 1.0)[:, None], 0.0)
-    return Qn @ Qn.T, nrm
+    cos = Qn @ Qn.T
+    return 0.5 * (cos + cos.T), nrm       # exactly symmetric (the reference's per-edge dot products are): the kernels read A[j][i] for A[i][j]
 
 
 class AngleGraph:

@@ -9,12 +9,24 @@
 //     L_ij = (Q_i . K_j + (Q_i . we) A_ij) / sqrt(F)      for j != i           (key_j + lin_edge(a_ij), target i, source j)
 //     alpha = softmax_j(L)   (torch_geometric.utils.softmax: exp(L - max) / (sum + 1e-16))
 //     O_i  = sum_j alpha_ij V_j + (sum_j alpha_ij A_ij) we + R_i ,   H = relu(O)
-// so the hot operations are N x N x F GEMMs (rocBLAS sgemm, loaded on first use: plain library GEMMs, exact fp32) and the fused
-// row kernels below (bias / row dot, masked softmax with the edge term, softmax backward with the edge reductions).
-// A [N, N] is the dense cosine matrix (diagonal ignored: the graph has no self loops).  The backward pass is hand-derived
-// (tests/test_angle.py checks it against fp64 autograd of the oracle's literal TransformerConv on the edge list).
-#include <dlfcn.h>
-
+// A [N, N] is the dense, SYMMETRIC cosine matrix (diagonal ignored: the graph has no self loops).
+//
+// Round 4: everything is hand-written for the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TFLOP/s peak);
+// rocBLAS is neither linked nor loaded, and no N x N matrix exists in HBM:
+//   * attn_kernel<F, MODE>   one wavefront per (block of 16 "Y" nodes, range of "X" blocks).  Every product is computed
+//       TRANSPOSED so that no tile ever changes its register layout: T[x][y] = X_x . Y_y lands with y in the lane and x in
+//       the register, which is exactly the B operand of the accumulation  acc[f][y] += W[x][f] T'[x][y].
+//         FWD  X = keys, Y = queries:  T = K Q^T -> online softmax over the X blocks (edge bias (Q . we) A, diagonal
+//              masked, side sum u = sum p A) -> acc += V^T p;  partial {m, l, u, acc} per range, merged by fwd_combine
+//         BQ   X = keys, Y = queries:  p from the saved row max / 1 / sum, dp = V dO^T + (dO . we) A,
+//              dz = p (dp - D) / sqrt(F) -> acc += K^T dz (dQ), r = sum dz A
+//         BKV  X = queries, Y = keys:  the same p, dz with the roles exchanged -> accV += dO^T p (dV), accK += Q^T dz (dK)
+//       The backward recomputes p from {row max, 1 / (sum + 1e-16)} as the sparse path does; D_i = dO_i . (alpha V)_i + u_i s_i.
+//   * gemm_kernel            one 64 x 64 x 16 LDS-tiled MFMA GEMM with general strides (X W^T, dY^T X, dY W), K split
+//       over workgroups where the output is small (weight gradients: K = N), a ones column for the bias gradients.
+// The backward pass is hand-derived (tests/test_angle.py checks it against fp64 autograd of the oracle's literal
+// TransformerConv on the edge list).  Deterministic: fixed ranges, fixed summation orders, no atomics.
+#include <algorithm>
 #include <cmath>
 
 #include "device_utils.h"
@@ -24,54 +36,10 @@ namespace mllp {
 namespace {
 
 constexpr int AT = 256;     // threads of the row kernels
+typedef float f4 __attribute__((ext_vector_type(4)));
 
-// rocBLAS is loaded on first use (dlopen): the sparse hot path of this library neither links nor loads it.  The four
-// entry points and the enum values below are rocBLAS' public C API (rocblas/internal/rocblas-types.h).
-struct Blas {
-    void* handle = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*sgemm)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*,
-                 int) = nullptr;
-};
-constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112, ROCBLAS_ATOMICS_NOT_ALLOWED = 0;
-
-const Blas& blas() {
-    static Blas b = [] {
-        Blas x;
-        // the copy that is already in the process first (torch loads its own under a versioned SONAME): two rocBLAS
-        // instances in one process would each keep their own kernels and handles
-        void* lib = nullptr;
-        for (const char* name : {"librocblas.so.5", "librocblas.so.4", "librocblas.so"})
-            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
-        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return x;
-        auto create = reinterpret_cast<int (*)(void**)>(dlsym(lib, "rocblas_create_handle"));
-        auto atomics = reinterpret_cast<int (*)(void*, int)>(dlsym(lib, "rocblas_set_atomics_mode"));
-        x.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(lib, "rocblas_set_stream"));
-        x.sgemm = reinterpret_cast<decltype(x.sgemm)>(dlsym(lib, "rocblas_sgemm"));
-        if (!create || !atomics || !x.set_stream || !x.sgemm || create(&x.handle) != 0) {
-            x.handle = nullptr;
-            return x;
-        }
-        atomics(x.handle, ROCBLAS_ATOMICS_NOT_ALLOWED);      // deterministic sums (no split-K atomics)
-        return x;
-    }();
-    return b;
-}
-
-// row-major C[M, N] = alpha * op(A) * op(B) + beta * C   (op(A): M x K, op(B): K x N)
-int gemm_rm(hipStream_t s, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
-            const float* B, int64_t ldb, float beta, float* C, int64_t ldc) {
-    if (M == 0 || N == 0) return MLLP_OK;
-    const Blas& b = blas();
-    if (!b.handle) return fail(MLLP_EHIP, "rocBLAS (librocblas.so) could not be loaded: AngleModel needs it for its dense GEMMs");
-    b.set_stream(b.handle, s);
-    // a row-major matrix is its transpose in column-major storage: C^T = op(B)^T op(A)^T
-    const int st = b.sgemm(b.handle, tb ? ROCBLAS_OP_T : ROCBLAS_OP_N, ta ? ROCBLAS_OP_T : ROCBLAS_OP_N, (int)N, (int)M, (int)K,
-                           &alpha, B, (int)ldb, A, (int)lda, &beta, C, (int)ldc);
-    return st == 0 ? MLLP_OK : fail(MLLP_EHIP, "rocblas_sgemm failed");
-}
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 f4zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -83,124 +51,398 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int w = 0; w < AT / 64; ++w) t += sh[w];
     return t;
 }
-__device__ __forceinline__ float block_max(float v, float* sh) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    float t = sh[0];
-    for (int w = 1; w < AT / 64; ++w) t = fmaxf(t, sh[w]);
-    return t;
+
+// =================================================================================================== GEMM
+// C[m][n] = sum over pairs p, k of A_p(m, k) B_p(n, k)  (+ bias[n]),  A_p(m, k) = A_p[m sam + k sak], B_p(n, k) = B_p[n sbn + k sbk]
+struct GemmProb {
+    const float* A[4];
+    const float* B[4];
+    float* C;                 // [M][ldc]           (ksplits == 1)
+    const float* bias;        // [N] or nullptr     (ksplits == 1)
+    int npairs;
+};
+struct GemmBatch {
+    GemmProb p[4];
+    int M, N, K;              // the same for every problem of the batch
+    long long sam, sak, sbn, sbk;
+    int ldc;
+    int ones_col;             // B(N - 1, k) = 1: the last output column is the column sum of A (bias gradients)
+    int ksplits, kchunk;      // K is cut into ksplits ranges of kchunk (a multiple of 16); > 1: partial sums
+    float* partial;           // [problem][ksplit][M][N]
+};
+constexpr int GT = 64, GK = 16, GS = GK + 1;
+
+template <bool AK1, bool BK1>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch g) {
+    __shared__ float As[GT * GS], Bs[GT * GS];
+    const GemmProb& pr = g.p[blockIdx.z];
+    const int tiles_n = (g.N + GT - 1) / GT;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int k_lo = blockIdx.y * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
+    f4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
+    for (int p = 0; p < pr.npairs; ++p) {
+        const float* __restrict__ A = pr.A[p];
+        const float* __restrict__ B = pr.B[p];
+        for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int m, k;
+                if (AK1) { m = t >> 2; k = (t & 3) * 4 + i; } else { k = t >> 4; m = (t & 15) * 4 + i; }
+                const bool ok = m0 + m < g.M && k0 + k < k_hi;
+                As[m * GS + k] = ok ? A[(long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak] : 0.0f;
+                int n, kb;
+                if (BK1) { n = t >> 2; kb = (t & 3) * 4 + i; } else { kb = t >> 4; n = (t & 15) * 4 + i; }
+                const bool okb = n0 + n < g.N && k0 + kb < k_hi;
+                float v = 0.0f;
+                if (okb) v = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : B[(long long)(n0 + n) * g.sbn + (long long)(k0 + kb) * g.sbk];
+                Bs[n * GS + kb] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float a = As[(16 * w + (lane & 15)) * GS + 4 * kk + (lane >> 4)];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4(a, Bs[(16 * nt + (lane & 15)) * GS + 4 * kk + (lane >> 4)], acc[nt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * w + 4 * (lane >> 4) + r, n = n0 + 16 * nt + (lane & 15);
+            if (m < g.M && n < g.N) {
+                if (g.ksplits == 1 && !g.ones_col) pr.C[(long long)m * g.ldc + n] = acc[nt][r] + (pr.bias ? pr.bias[n] : 0.0f);
+                else g.partial[(((long long)blockIdx.z * g.ksplits + blockIdx.y) * g.M + m) * g.N + n] = acc[nt][r];
+            }
+        }
 }
 
-// C[r, :] += b ; optionally d[r] = C[r, :] . w      (one workgroup per row)
-__global__ __launch_bounds__(AT) void bias_dot_kernel(int F, float* __restrict__ C, const float* __restrict__ b,
-                                                      const float* __restrict__ w, float* __restrict__ d) {
-    __shared__ float sh[AT / 64];
-    float* row = C + (size_t)blockIdx.x * F;
-    float acc = 0.0f;
-    for (int c = threadIdx.x; c < F; c += AT) {
-        const float v = row[c] + (b ? b[c] : 0.0f);
-        row[c] = v;
-        if (w) acc = fmaf(v, w[c], acc);
-    }
-    if (d) {
-        const float t = block_sum(acc, sh);
-        if (threadIdx.x == 0) d[blockIdx.x] = t;
+// C[m][n] = beta C[m][n] + sum over the K ranges; with a ones column: column N - 1 goes to colsum[m] instead
+struct ReduceBatch {
+    float* C[4];
+    float* colsum[4];
+    int M, N, ldc, ksplits, ones_col;
+    float beta;
+    const float* partial;
+};
+__global__ __launch_bounds__(AT) void gemm_reduce_kernel(ReduceBatch g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long i = (long long)blockIdx.x * AT + threadIdx.x; i < total; i += (long long)gridDim.x * AT) {
+        const int m = (int)(i / g.N), n = (int)(i % g.N);
+        float v = 0.0f;
+        for (int s = 0; s < g.ksplits; ++s) v += g.partial[(((long long)blockIdx.z * g.ksplits + s) * g.M + m) * g.N + n];
+        float* dst = (g.ones_col && n == g.N - 1) ? g.colsum[blockIdx.z] + m : g.C[blockIdx.z] + (long long)m * g.ldc + n;
+        *dst = g.beta != 0.0f ? g.beta * *dst + v : v;
     }
 }
 
-// Z[i, :] (= Q_i . K_j) -> alpha[i, :] in place, s[i] = sum_j alpha_ij A_ij     (row i: target, diagonal masked)
-__global__ __launch_bounds__(AT) void softmax_edge_kernel(int N, float scale, float* __restrict__ Z,
-                                                          const float* __restrict__ A, const float* __restrict__ qe,
-                                                          float* __restrict__ s_out) {
-    __shared__ float sh[AT / 64];
+int check(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MLLP_OK : hip_fail(e, what);
+}
+
+// strides of the three forms on row-major operands
+struct GemmShape {
+    int M, N, K;
+    long long sam, sak, sbn, sbk;
+    int ldc;
+};
+int launch_gemm(hipStream_t s, const GemmShape& sh, int nprob, const GemmProb* probs, int ones_col, int ksplits, float beta,
+                float* partial, float* const* colsum) {
+    if (sh.M == 0 || sh.N == 0) return MLLP_OK;
+    GemmBatch g;
+    for (int i = 0; i < nprob; ++i) g.p[i] = probs[i];
+    g.M = sh.M; g.N = sh.N; g.K = sh.K; g.sam = sh.sam; g.sak = sh.sak; g.sbn = sh.sbn; g.sbk = sh.sbk; g.ldc = sh.ldc;
+    g.ones_col = ones_col;
+    g.ksplits = ksplits;
+    g.kchunk = ((sh.K + ksplits - 1) / ksplits + GK - 1) / GK * GK;
+    g.partial = partial;
+    const dim3 grid((unsigned)(((sh.M + GT - 1) / GT) * ((sh.N + GT - 1) / GT)), (unsigned)ksplits, (unsigned)nprob);
+    const bool ak1 = sh.sak == 1, bk1 = sh.sbk == 1;
+    if (ak1 && bk1) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (ak1) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (bk1) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+    int rc;
+    if ((rc = check("angle gemm"))) return rc;
+    if (ksplits > 1 || ones_col) {
+        ReduceBatch r;
+        for (int i = 0; i < nprob; ++i) { r.C[i] = probs[i].C; r.colsum[i] = colsum ? colsum[i] : nullptr; }
+        r.M = sh.M; r.N = sh.N; r.ldc = sh.ldc; r.ksplits = ksplits; r.ones_col = ones_col; r.beta = beta; r.partial = partial;
+        const long long total = (long long)sh.M * sh.N;
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)std::min<long long>((total + AT - 1) / AT, 2048), 1, (unsigned)nprob),
+                           dim3(AT), 0, s, r);
+        return check("angle gemm reduce");
+    }
+    return MLLP_OK;
+}
+
+// =================================================================================================== attention
+constexpr int MODE_FWD = 0, MODE_BQ = 1, MODE_BKV = 2;
+struct AttnArgs {
+    const float *Y1, *Y2;      // rows of the Y nodes   FWD: Q, -     BQ: Q, dO     BKV: K, V
+    const float *X1, *X2;      // rows of the X nodes   FWD: K, -     BQ: K, V      BKV: Q, dO
+    const float *W1, *W2;      // accumulated rows      FWD: V, -     BQ: K, -      BKV: dO (-> dV), Q (-> dK)
+    const float* cos;          // [N][N]
+    const float* we;           // [F]
+    const float *qe, *m, *inv, *u, *D;     // per node (written by FWD / the row kernels; read by BQ / BKV)
+    float *part1, *part2;      // [ranges][N][F]
+    float* stats;              // [ranges][N][4]  FWD: {m, l, u}   BQ: {r}
+    float* qe_out;             // FWD: [N]
+    int N, xb_per_range;
+    float scale;
+};
+
+// rows row0 .. row0 + 15 of M as MFMA operands of a dot product over the features: lane l holds row l & 15, features
+// 16 j + 4 (l >> 4) .. + 3 -- MFMA (j, c) then multiplies feature 16 j + 4 (l >> 4) + c of both operands
+template <int F>
+__device__ __forceinline__ void load_frag(f4 (&fr)[F / 16], const float* __restrict__ M, int row0, int N, int lane) {
+    const int row = row0 + (lane & 15);
+    const float* p = M + (size_t)row * F + 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < F / 16; ++j) fr[j] = row < N ? *reinterpret_cast<const f4*>(p + 16 * j) : f4zero();
+}
+// T[x][y] = X_x . Y_y:  lane l, register r  <->  x = 4 (l >> 4) + r,  y = l & 15
+template <int F>
+__device__ __forceinline__ f4 tile_dot(const f4 (&xa)[F / 16], const f4 (&yb)[F / 16]) {
+    f4 t0 = f4zero(), t1 = f4zero();          // two chains: the dependent-accumulator latency (40) exceeds the issue time (32)
+#pragma unroll
+    for (int j = 0; j < F / 16; ++j) {
+        t0 = mfma4(xa[j][0], yb[j][0], t0);
+        t1 = mfma4(xa[j][1], yb[j][1], t1);
+        t0 = mfma4(xa[j][2], yb[j][2], t0);
+        t1 = mfma4(xa[j][3], yb[j][3], t1);
+    }
+    return t0 + t1;
+}
+// acc[f][y] += sum_x W[x][f] t[x][y]:  MFMA r takes x = x0 + 4 (l >> 4) + r as its k slot; the A operand of lane (g, i) is
+// W[x][64 u + 4 i + c] (one 16-byte load gives c = 0..3, i.e. the four tiles (u, c)); tile (u, c), register rr of lane (g, y)
+// then holds f = 64 u + 16 g + 4 rr + c.
+template <int F>
+__device__ __forceinline__ void accumulate(f4 (&acc)[(F + 63) / 64 * 4], const float* __restrict__ W, int x0, int N, int lane, const f4& t) {
+    constexpr int FU = (F + 63) / 64;
+    const int i4 = 4 * (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = x0 + 4 * (lane >> 4) + r;
+        const float* p = W + (size_t)x * F + i4;
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const f4 w = (x < N && 64 * u + i4 < F) ? *reinterpret_cast<const f4*>(p + 64 * u) : f4zero();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * u + c] = mfma4(w[c], t[r], acc[4 * u + c]);
+        }
+    }
+}
+template <int F>
+__device__ __forceinline__ void store_acc(const f4 (&acc)[(F + 63) / 64 * 4], float* __restrict__ out, int y, int N, int lane) {
+    constexpr int FU = (F + 63) / 64;
+    if (y >= N) return;
+#pragma unroll
+    for (int u = 0; u < FU; ++u)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int f0 = 64 * u + 16 * (lane >> 4) + 4 * rr;
+            if (f0 < F) *reinterpret_cast<f4*>(out + (size_t)y * F + f0) = f4{acc[4 * u][rr], acc[4 * u + 1][rr], acc[4 * u + 2][rr], acc[4 * u + 3][rr]};
+        }
+}
+__device__ __forceinline__ float group_max(float v) {      // over the four lanes l, l ^ 16, l ^ 32, l ^ 48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+template <int F, int MODE>
+__global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
+    constexpr int FJ = F / 16, NA = (F + 63) / 64 * 4;
+    const int lane = threadIdx.x, g = lane >> 4;
+    const int N = a.N;
+    const int y0 = blockIdx.x * 16, y = y0 + (lane & 15);
+    const int n_xb = (N + 15) / 16;
+    const int xb_lo = blockIdx.y * a.xb_per_range, xb_hi = min(n_xb, xb_lo + a.xb_per_range);
+    const bool yok = y < N;
+    const float* __restrict__ cosrow = a.cos + (size_t)min(y, N - 1) * N;
+
+    f4 y1[FJ], y2[MODE == MODE_FWD ? 1 : FJ];
+    load_frag<F>(y1, a.Y1, y0, N, lane);
+    if constexpr (MODE != MODE_FWD) load_frag<F>(y2, a.Y2, y0, N, lane);
+    f4 acc1[NA], acc2[MODE == MODE_BKV ? NA : 1];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc1[i] = f4zero();
+    if constexpr (MODE == MODE_BKV)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc2[i] = f4zero();
+
+    // per-Y scalars
+    float qe_y = 0.f, m_y = 0.f, inv_y = 0.f, u_y = 0.f, D_y = 0.f;
+    if constexpr (MODE == MODE_FWD) {          // qe = Q . we for the own rows (every lane of the row ends with the total)
+        float d = 0.f;
+        const float* wp = a.we + 4 * g;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const f4 wv = *reinterpret_cast<const f4*>(wp + 16 * j);
+            d = fmaf(y1[j][0], wv[0], d); d = fmaf(y1[j][1], wv[1], d); d = fmaf(y1[j][2], wv[2], d); d = fmaf(y1[j][3], wv[3], d);
+        }
+        qe_y = group_sum(d);
+        if (blockIdx.y == 0 && g == 0 && yok) a.qe_out[y] = qe_y;
+    } else if constexpr (MODE == MODE_BQ) {
+        if (yok) { qe_y = a.qe[y]; m_y = a.m[y]; inv_y = a.inv[y]; u_y = a.u[y]; D_y = a.D[y]; }
+    }
+    float run_m = NEG_BIG, run_l = 0.f, run_u = 0.f, run_r = 0.f;
+
+    for (int xb = xb_lo; xb < xb_hi; ++xb) {
+        const int x0 = xb * 16, xg = x0 + 4 * g;
+        f4 xa[FJ];
+        load_frag<F>(xa, a.X1, x0, N, lane);
+        f4 t1 = tile_dot<F>(xa, y1);
+        f4 t2 = f4zero();
+        if constexpr (MODE != MODE_FWD) {
+            load_frag<F>(xa, a.X2, x0, N, lane);
+            t2 = tile_dot<F>(xa, y2);
+        }
+        float cv[4];
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = xg + r;
+            ok[r] = yok && x < N && x != y;
+            cv[r] = (yok && x < N) ? cosrow[x] : 0.0f;        // (the matrix is symmetric: A[y][x] serves both orientations)
+        }
+        if constexpr (MODE == MODE_FWD) {
+            float L[4], lm = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                L[r] = ok[r] ? fmaf(qe_y, cv[r], t1[r]) * a.scale : NEG_BIG;
+                lm = fmaxf(lm, L[r]);
+            }
+            lm = group_max(lm);
+            const float mn = fmaxf(run_m, lm);
+            const float al = exp_acc(run_m - mn);
+            run_m = mn;
+            f4 p;
+            float ps = 0.f, pu = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = ok[r] ? exp_acc(L[r] - mn) : 0.0f;
+                ps += p[r];
+                pu = fmaf(p[r], cv[r], pu);
+            }
+            run_l = fmaf(run_l, al, ps);
+            run_u = fmaf(run_u, al, pu);
+            if (__any(al != 1.0f)) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc1[i] *= al;
+            }
+            accumulate<F>(acc1, a.W1, x0, N, lane, p);
+        } else {
+            float qe_[4], m_[4], inv_[4], u_[4], D_[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (MODE == MODE_BQ) { qe_[r] = qe_y; m_[r] = m_y; inv_[r] = inv_y; u_[r] = u_y; D_[r] = D_y; }
+                else {
+                    const int x = min(xg + r, N - 1);
+                    qe_[r] = a.qe[x]; m_[r] = a.m[x]; inv_[r] = a.inv[x]; u_[r] = a.u[x]; D_[r] = a.D[x];
+                }
+            }
+            f4 p, dz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float L = fmaf(qe_[r], cv[r], t1[r]) * a.scale;
+                p[r] = ok[r] ? exp_acc(L - m_[r]) * inv_[r] : 0.0f;
+                const float dp = fmaf(u_[r], cv[r], t2[r]);
+                dz[r] = p[r] * (dp - D_[r]) * a.scale;
+                run_r = fmaf(dz[r], cv[r], run_r);
+            }
+            if constexpr (MODE == MODE_BQ) accumulate<F>(acc1, a.W1, x0, N, lane, dz);
+            else {
+                accumulate<F>(acc1, a.W1, x0, N, lane, p);
+                accumulate<F>(acc2, a.W2, x0, N, lane, dz);
+            }
+        }
+    }
+    const size_t slab = (size_t)blockIdx.y * N;
+    store_acc<F>(acc1, a.part1 + slab * F, y, N, lane);
+    if constexpr (MODE == MODE_BKV) store_acc<F>(acc2, a.part2 + slab * F, y, N, lane);
+    if constexpr (MODE == MODE_FWD) {
+        run_l = group_sum(run_l);
+        run_u = group_sum(run_u);
+        if (g == 0 && yok) *reinterpret_cast<f4*>(a.stats + (slab + y) * 4) = f4{run_m, run_l, run_u, 0.f};
+    } else if constexpr (MODE == MODE_BQ) {
+        run_r = group_sum(run_r);
+        if (g == 0 && yok) a.stats[(slab + y) * 4] = run_r;
+    }
+}
+
+// merge of the forward ranges and the layer's epilogue: Oa = alpha V, s = sum alpha A, H = relu(Oa + s we + R)
+__global__ __launch_bounds__(AT) void fwd_combine_kernel(int N, int F, int ranges, const float* __restrict__ part,
+                                                         const float* __restrict__ stats, const float* __restrict__ R,
+                                                         const float* __restrict__ we, float* __restrict__ Oa,
+                                                         float* __restrict__ H, float* __restrict__ m_out,
+                                                         float* __restrict__ inv_out, float* __restrict__ s_out) {
     const int i = blockIdx.x;
-    float* z = Z + (size_t)i * N;
-    const float* a = A + (size_t)i * N;
-    const float q = qe[i];
-    float m = -3.0e38f;
-    for (int j = threadIdx.x; j < N; j += AT)
-        if (j != i) m = fmaxf(m, fmaf(q, a[j], z[j]) * scale);
-    m = block_max(m, sh);
-    float sum = 0.0f;
-    for (int j = threadIdx.x; j < N; j += AT) {
-        float e = 0.0f;
-        if (j != i) e = exp_acc(fmaf(q, a[j], z[j]) * scale - m);
-        z[j] = e;
-        sum += e;
+    float M = NEG_BIG;
+    for (int s = 0; s < ranges; ++s) M = fmaxf(M, stats[((size_t)s * N + i) * 4]);
+    float l = 0.f, u = 0.f;
+    for (int s = 0; s < ranges; ++s) {
+        const float* st = stats + ((size_t)s * N + i) * 4;
+        const float w = exp_acc(st[0] - M);
+        l = fmaf(st[1], w, l);
+        u = fmaf(st[2], w, u);
     }
-    sum = block_sum(sum, sh);
-    const float inv = 1.0f / (sum + 1e-16f);        // torch_geometric.utils.softmax
-    float sa = 0.0f;
-    for (int j = threadIdx.x; j < N; j += AT) {
-        const float al = z[j] * inv;
-        z[j] = al;
-        sa = fmaf(al, a[j], sa);                    // alpha_ii = 0
+    const float inv = 1.0f / (l + 1e-16f);        // torch_geometric.utils.softmax
+    const float sv = u * inv;
+    if (threadIdx.x == 0) { m_out[i] = M; inv_out[i] = inv; s_out[i] = sv; }
+    for (int c = threadIdx.x; c < F; c += AT) {
+        float o = 0.f;
+        for (int s = 0; s < ranges; ++s) o = fmaf(part[((size_t)s * N + i) * F + c], exp_acc(stats[((size_t)s * N + i) * 4] - M), o);
+        o *= inv;
+        Oa[(size_t)i * F + c] = o;
+        H[(size_t)i * F + c] = fmaxf(fmaf(sv, we[c], o + R[(size_t)i * F + c]), 0.0f);
     }
-    sa = block_sum(sa, sh);
-    if (threadIdx.x == 0) s_out[i] = sa;
 }
 
-// H[i, :] = relu(H[i, :] + bs + s_i we)
-__global__ __launch_bounds__(AT) void out_relu_kernel(int F, float* __restrict__ H, const float* __restrict__ bs,
-                                                      const float* __restrict__ we, const float* __restrict__ s) {
-    float* row = H + (size_t)blockIdx.x * F;
-    const float si = s[blockIdx.x];
-    for (int c = threadIdx.x; c < F; c += AT) row[c] = fmaxf(fmaf(si, we[c], row[c] + bs[c]), 0.0f);
+// out[i][:] = sum over the ranges of part (+ r_i w, r_i = sum over the ranges of stats)
+__global__ __launch_bounds__(AT) void sum_ranges_kernel(int N, int F, int ranges, const float* __restrict__ part,
+                                                        const float* __restrict__ stats, const float* __restrict__ w,
+                                                        float* __restrict__ out, float* __restrict__ r_out) {
+    const int i = blockIdx.x;
+    float r = 0.f;
+    if (stats) {
+        for (int s = 0; s < ranges; ++s) r += stats[((size_t)s * N + i) * 4];
+        if (threadIdx.x == 0) r_out[i] = r;
+    }
+    for (int c = threadIdx.x; c < F; c += AT) {
+        float o = 0.f;
+        for (int s = 0; s < ranges; ++s) o += part[((size_t)s * N + i) * F + c];
+        out[(size_t)i * F + c] = stats ? fmaf(r, w[c], o) : o;
+    }
 }
 
-// dO = dH * (H > 0) in place; u[i] = dO_i . we
+// dO = dH * (H > 0) in place; u[i] = dO_i . we; D[i] = dO_i . Oa_i + u_i s_i
 __global__ __launch_bounds__(AT) void relu_bwd_kernel(int F, float* __restrict__ dH, const float* __restrict__ H,
-                                                      const float* __restrict__ we, float* __restrict__ u) {
+                                                      const float* __restrict__ Oa, const float* __restrict__ we,
+                                                      const float* __restrict__ s, float* __restrict__ u, float* __restrict__ D) {
     __shared__ float sh[AT / 64];
     float* row = dH + (size_t)blockIdx.x * F;
     const float* h = H + (size_t)blockIdx.x * F;
-    float acc = 0.0f;
+    const float* oa = Oa + (size_t)blockIdx.x * F;
+    float au = 0.0f, ad = 0.0f;
     for (int c = threadIdx.x; c < F; c += AT) {
         const float v = h[c] > 0.0f ? row[c] : 0.0f;
         row[c] = v;
-        acc = fmaf(v, we[c], acc);
+        au = fmaf(v, we[c], au);
+        ad = fmaf(v, oa[c], ad);
     }
-    const float t = block_sum(acc, sh);
-    if (threadIdx.x == 0) u[blockIdx.x] = t;
-}
-
-// G[i, :] (= dO_i . V_j) -> dZ[i, :] in place; r[i] = sum_j dZ_ij A_ij
-//   g_ij = G_ij + u_i A_ij ,  dL_ij = alpha_ij (g_ij - sum_k alpha_ik g_ik) ,  dZ = dL * scale
-__global__ __launch_bounds__(AT) void softmax_bwd_kernel(int N, float scale, float* __restrict__ G,
-                                                         const float* __restrict__ alpha, const float* __restrict__ A,
-                                                         const float* __restrict__ u, float* __restrict__ r_out) {
-    __shared__ float sh[AT / 64];
-    const int i = blockIdx.x;
-    float* g = G + (size_t)i * N;
-    const float* al = alpha + (size_t)i * N;
-    const float* a = A + (size_t)i * N;
-    const float ui = u[i];
-    float t = 0.0f;
-    for (int j = threadIdx.x; j < N; j += AT) t = fmaf(al[j], fmaf(ui, a[j], g[j]), t);
-    t = block_sum(t, sh);
-    float ra = 0.0f;
-    for (int j = threadIdx.x; j < N; j += AT) {
-        const float dz = al[j] * (fmaf(ui, a[j], g[j]) - t) * scale;
-        g[j] = dz;
-        ra = fmaf(dz, a[j], ra);
-    }
-    ra = block_sum(ra, sh);
-    if (threadIdx.x == 0) r_out[i] = ra;
-}
-
-// C[i, :] += r_i * w
-__global__ __launch_bounds__(AT) void add_outer_kernel(int F, float* __restrict__ C, const float* __restrict__ r,
-                                                       const float* __restrict__ w) {
-    float* row = C + (size_t)blockIdx.x * F;
-    const float ri = r[blockIdx.x];
-    for (int c = threadIdx.x; c < F; c += AT) row[c] = fmaf(ri, w[c], row[c]);
-}
-
-__global__ __launch_bounds__(AT) void fill_kernel(int64_t n, float v, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) out[i] = v;
+    const float tu = block_sum(au, sh);
+    const float td = block_sum(ad, sh);
+    if (threadIdx.x == 0) { u[blockIdx.x] = tu; D[blockIdx.x] = fmaf(tu, s[blockIdx.x], td); }
 }
 
 // logits[i] = H[i, :] . w + b  for i < n_out
@@ -228,11 +470,6 @@ __global__ __launch_bounds__(AT) void sum_kernel(int64_t n, const float* __restr
     if (threadIdx.x == 0) out[0] = t;
 }
 
-int check(const char* what) {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? MLLP_OK : hip_fail(e, what);
-}
-
 // flat parameters in PyG state_dict order (mllp_amd/angle.py::AngleModel): per conv lin_key {W [F,C], b [F]}, lin_query,
 // lin_value, lin_edge {W [F,1]}, lin_skip {W, b}; then fc {W [1,F], b [1]}
 struct ConvP {
@@ -254,53 +491,93 @@ P conv_at(T* base, int C, int F) {
     return p;
 }
 
-// per layer: Q, K, V, H [N, F]; alpha [N, N]; s [N]
+// ranges of X blocks per Y block: enough wavefronts for every SIMD of the chip (one wavefront per SIMD: the kernels hold
+// up to ~350 registers), never more ranges than X blocks, at most 32
+int attn_ranges(int64_t N) {
+    const int64_t nb = (N + 15) / 16;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 32), (2048 + nb - 1) / nb));
+}
+int gemm_ksplits(int64_t K) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, K / 128)); }
+
+// per layer: Q, K, V, R, Oa, H [N, F]; m, inv, s, qe [N]
 struct LayerWs {
-    float *Q, *K, *V, *H, *alpha, *s;
+    float *Q, *K, *V, *R, *Oa, *H, *m, *inv, *s, *qe;
 };
 struct AngleWs {
     LayerWs L[3];
     float *dA, *dB;            // [N, F] gradient of a layer's output / of its input
     float *dQ, *dK, *dV;       // [N, F]
-    float *G;                  // [N, N]
-    float *u, *r, *qe, *ones;  // [N]
+    float *u, *r, *D;          // [N]
+    float *part1, *part2;      // [ranges][N][F]
+    float* stats;              // [ranges][N][4]
+    float* gpart;              // [4][ksplits][F][F + 1]
 };
 int64_t up(int64_t x) { return (x + 63) & ~int64_t(63); }
 int64_t angle_ws_floats(int64_t N, int F) {
-    return 3 * (4 * up(N * F) + up(N * N) + up(N)) + 5 * up(N * F) + up(N * N) + 4 * up(N);
+    const int64_t R = attn_ranges(N), ks = gemm_ksplits(N);
+    return 3 * (6 * up(N * F) + 4 * up(N)) + 5 * up(N * F) + 3 * up(N) + 2 * up(R * N * F) + up(R * N * 4) + up(4 * ks * F * (F + 1));
 }
 AngleWs angle_carve(float* base, int64_t N, int F) {
+    const int64_t R = attn_ranges(N);
     AngleWs w;
     float* p = base;
     for (int l = 0; l < 3; ++l) {
-        w.L[l].Q = p; p += up(N * F); w.L[l].K = p; p += up(N * F); w.L[l].V = p; p += up(N * F);
-        w.L[l].H = p; p += up(N * F); w.L[l].alpha = p; p += up(N * N); w.L[l].s = p; p += up(N);
+        LayerWs& L = w.L[l];
+        L.Q = p; p += up(N * F); L.K = p; p += up(N * F); L.V = p; p += up(N * F); L.R = p; p += up(N * F);
+        L.Oa = p; p += up(N * F); L.H = p; p += up(N * F);
+        L.m = p; p += up(N); L.inv = p; p += up(N); L.s = p; p += up(N); L.qe = p; p += up(N);
     }
     w.dA = p; p += up(N * F); w.dB = p; p += up(N * F);
     w.dQ = p; p += up(N * F); w.dK = p; p += up(N * F); w.dV = p; p += up(N * F);
-    w.G = p; p += up(N * N);
-    w.u = p; p += up(N); w.r = p; p += up(N); w.qe = p; p += up(N); w.ones = p;
+    w.u = p; p += up(N); w.r = p; p += up(N); w.D = p; p += up(N);
+    w.part1 = p; p += up(R * N * F); w.part2 = p; p += up(R * N * F);
+    w.stats = p; p += up(R * N * 4);
+    w.gpart = p;
     return w;
 }
 
+template <int MODE>
+int launch_attn(hipStream_t s, int F, const AttnArgs& a) {
+    const dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)(((a.N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range));
+    switch (F) {
+        case 16: hipLaunchKernelGGL((attn_kernel<16, MODE>), grid, dim3(64), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((attn_kernel<32, MODE>), grid, dim3(64), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((attn_kernel<64, MODE>), grid, dim3(64), 0, s, a); break;
+        case 128: hipLaunchKernelGGL((attn_kernel<128, MODE>), grid, dim3(64), 0, s, a); break;
+        case 256: hipLaunchKernelGGL((attn_kernel<256, MODE>), grid, dim3(64), 0, s, a); break;
+        default: return fail(MLLP_EINVAL, "AngleModel: feat_dim must be 16, 32, 64, 128 or 256");
+    }
+    return check("angle attention");
+}
+AttnArgs attn_base(int64_t N, int F, const float* cos, const ConvP& p, const LayerWs& L, const AngleWs& w) {
+    AttnArgs a{};
+    a.cos = cos; a.we = p.we;
+    a.qe = L.qe; a.m = L.m; a.inv = L.inv; a.u = w.u; a.D = w.D;
+    a.part1 = w.part1; a.part2 = w.part2; a.stats = w.stats; a.qe_out = L.qe;
+    a.N = (int)N;
+    const int nb = (int)((N + 15) / 16), R = attn_ranges(N);
+    a.xb_per_range = (nb + R - 1) / R;
+    a.scale = 1.0f / sqrtf((float)F);
+    return a;
+}
+
 int conv_forward(hipStream_t s, int64_t N, int C, int F, const float* A, const float* X, const ConvP& p, const LayerWs& L,
-                 float* qe) {
+                 const AngleWs& w) {
     int rc;
-    const float scale = 1.0f / sqrtf((float)F);
-    if ((rc = gemm_rm(s, false, true, N, F, C, 1.0f, X, C, p.Wq, C, 0.0f, L.Q, F))) return rc;
-    if ((rc = gemm_rm(s, false, true, N, F, C, 1.0f, X, C, p.Wk, C, 0.0f, L.K, F))) return rc;
-    if ((rc = gemm_rm(s, false, true, N, F, C, 1.0f, X, C, p.Wv, C, 0.0f, L.V, F))) return rc;
-    if ((rc = gemm_rm(s, false, true, N, F, C, 1.0f, X, C, p.Ws, C, 0.0f, L.H, F))) return rc;       // R, completed below
-    hipLaunchKernelGGL(bias_dot_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, L.Q, p.bq, p.we, qe);
-    hipLaunchKernelGGL(bias_dot_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, L.K, p.bk, (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(bias_dot_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, L.V, p.bv, (const float*)nullptr, (float*)nullptr);
-    if ((rc = check("angle bias"))) return rc;
-    if ((rc = gemm_rm(s, false, true, N, N, F, 1.0f, L.Q, F, L.K, F, 0.0f, L.alpha, N))) return rc;   // Z = Q K^T
-    hipLaunchKernelGGL(softmax_edge_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, scale, L.alpha, A, qe, L.s);
-    if ((rc = check("angle softmax"))) return rc;
-    if ((rc = gemm_rm(s, false, false, N, F, N, 1.0f, L.alpha, N, L.V, F, 1.0f, L.H, F))) return rc;  // H = R + alpha V
-    hipLaunchKernelGGL(out_relu_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, L.H, p.bs, p.we, L.s);
-    return check("angle out");
+    // Q, K, V, R = X W^T + b in one launch
+    GemmProb pr[4] = {};
+    const float* Ws_[4] = {p.Wq, p.Wk, p.Wv, p.Ws};
+    const float* bs_[4] = {p.bq, p.bk, p.bv, p.bs};
+    float* out[4] = {L.Q, L.K, L.V, L.R};
+    for (int i = 0; i < 4; ++i) { pr[i].A[0] = X; pr[i].B[0] = Ws_[i]; pr[i].C = out[i]; pr[i].bias = bs_[i]; pr[i].npairs = 1; }
+    if ((rc = launch_gemm(s, GemmShape{(int)N, F, C, C, 1, C, 1, F}, 4, pr, 0, 1, 0.0f, nullptr, nullptr))) return rc;
+    AttnArgs a = attn_base(N, F, A, p, L, w);
+    a.Y1 = L.Q; a.X1 = L.K; a.W1 = L.V;
+    if ((rc = launch_attn<MODE_FWD>(s, F, a))) return rc;
+    const int ranges = (int)(((N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range);
+    hipLaunchKernelGGL(fwd_combine_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, w.stats, L.R, p.we, L.Oa,
+                       L.H, L.m, L.inv, L.s);
+    return check("angle fwd_combine");
 }
 
 // dH (in: gradient of the layer's output, overwritten with dO) -> parameter gradients (accumulated when acc) and, if dX,
@@ -308,38 +585,47 @@ int conv_forward(hipStream_t s, int64_t N, int C, int F, const float* A, const f
 int conv_backward(hipStream_t s, int64_t N, int C, int F, const float* A, const float* X, const ConvP& p, const LayerWs& L,
                   const AngleWs& w, float* dH, float* dX, const ConvG& g, bool acc) {
     int rc;
-    const float scale = 1.0f / sqrtf((float)F);
     const float beta = acc ? 1.0f : 0.0f;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, dH, L.H, p.we, w.u);    // dO, u = dO . we
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, dH, L.H, L.Oa, p.we, L.s, w.u, w.D);   // dO, u, D
     if ((rc = check("angle relu_bwd"))) return rc;
-    // skip path and value path
-    if ((rc = gemm_rm(s, true, false, F, C, N, 1.0f, dH, F, X, C, beta, g.Ws, C))) return rc;         // dWs = dO^T X
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, w.ones, N, dH, F, beta, g.bs, F))) return rc;     // dbs = 1^T dO
-    if ((rc = gemm_rm(s, true, false, N, F, N, 1.0f, L.alpha, N, dH, F, 0.0f, w.dV, F))) return rc;   // dV = alpha^T dO
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, L.s, N, dH, F, beta, g.we, F))) return rc;      // dwe = s^T dO
-    // attention weights
-    if ((rc = gemm_rm(s, false, true, N, N, F, 1.0f, dH, F, L.V, F, 0.0f, w.G, N))) return rc;        // G = dO V^T
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, scale, w.G, L.alpha, A, w.u, w.r);
-    if ((rc = check("angle softmax_bwd"))) return rc;
-    if ((rc = gemm_rm(s, false, false, N, F, N, 1.0f, w.G, N, L.K, F, 0.0f, w.dQ, F))) return rc;     // dQ = dZ K + r we^T
-    hipLaunchKernelGGL(add_outer_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, w.dQ, w.r, p.we);
-    if ((rc = gemm_rm(s, true, false, N, F, N, 1.0f, w.G, N, L.Q, F, 0.0f, w.dK, F))) return rc;      // dK = dZ^T Q
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, w.r, N, L.Q, F, 1.0f, g.we, F))) return rc;     // dwe += r^T Q
-    // weights of the three projections
-    if ((rc = gemm_rm(s, true, false, F, C, N, 1.0f, w.dQ, F, X, C, beta, g.Wq, C))) return rc;
-    if ((rc = gemm_rm(s, true, false, F, C, N, 1.0f, w.dK, F, X, C, beta, g.Wk, C))) return rc;
-    if ((rc = gemm_rm(s, true, false, F, C, N, 1.0f, w.dV, F, X, C, beta, g.Wv, C))) return rc;
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, w.ones, N, w.dQ, F, beta, g.bq, F))) return rc;
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, w.ones, N, w.dK, F, beta, g.bk, F))) return rc;
-    if ((rc = gemm_rm(s, false, false, 1, F, N, 1.0f, w.ones, N, w.dV, F, beta, g.bv, F))) return rc;
-    if (dX) {                                                                                         // dX = sum d* W*
-        if ((rc = gemm_rm(s, false, false, N, C, F, 1.0f, dH, F, p.Ws, C, 0.0f, dX, C))) return rc;
-        if ((rc = gemm_rm(s, false, false, N, C, F, 1.0f, w.dQ, F, p.Wq, C, 1.0f, dX, C))) return rc;
-        if ((rc = gemm_rm(s, false, false, N, C, F, 1.0f, w.dK, F, p.Wk, C, 1.0f, dX, C))) return rc;
-        if ((rc = gemm_rm(s, false, false, N, C, F, 1.0f, w.dV, F, p.Wv, C, 1.0f, dX, C))) return rc;
+    AttnArgs a = attn_base(N, F, A, p, L, w);
+    const int ranges = (int)(((N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range);
+    // dQ = dz K + r we^T,  r = sum dz A
+    a.Y1 = L.Q; a.Y2 = dH; a.X1 = L.K; a.X2 = L.V; a.W1 = L.K;
+    if ((rc = launch_attn<MODE_BQ>(s, F, a))) return rc;
+    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, w.stats, p.we, w.dQ, w.r);
+    // dV = alpha^T dO,  dK = dz^T Q
+    a.Y1 = L.K; a.Y2 = L.V; a.X1 = L.Q; a.X2 = dH; a.W1 = dH; a.W2 = L.Q;
+    if ((rc = launch_attn<MODE_BKV>(s, F, a))) return rc;
+    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, (const float*)nullptr,
+                       (const float*)nullptr, w.dV, (float*)nullptr);
+    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part2, (const float*)nullptr,
+                       (const float*)nullptr, w.dK, (float*)nullptr);
+    if ((rc = check("angle sum_ranges"))) return rc;
+    const int ks = gemm_ksplits(N);
+    {   // dW = dY^T X and db = 1^T dY of the four projections in one launch (K = N, split; the ones column gives db)
+        GemmProb pr[4] = {};
+        const float* dY[4] = {w.dQ, w.dK, w.dV, dH};
+        float* dW[4] = {g.Wq, g.Wk, g.Wv, g.Ws};
+        float* db[4] = {g.bq, g.bk, g.bv, g.bs};
+        for (int i = 0; i < 4; ++i) { pr[i].A[0] = dY[i]; pr[i].B[0] = X; pr[i].C = dW[i]; pr[i].npairs = 1; }
+        if ((rc = launch_gemm(s, GemmShape{F, C + 1, (int)N, 1, F, 1, C, C}, 4, pr, 1, ks, beta, w.gpart, db))) return rc;
+    }
+    {   // dwe = dO^T s + Q^T r
+        GemmProb pr[1] = {};
+        pr[0].A[0] = dH; pr[0].B[0] = L.s; pr[0].A[1] = L.Q; pr[0].B[1] = w.r; pr[0].C = g.we; pr[0].npairs = 2;
+        if ((rc = launch_gemm(s, GemmShape{F, 1, (int)N, 1, F, 1, 1, 1}, 1, pr, 0, std::max(ks, 2), beta, w.gpart, nullptr))) return rc;
+    }
+    if (dX) {   // dX = dO Ws + dQ Wq + dK Wk + dV Wv
+        GemmProb pr[1] = {};
+        pr[0].A[0] = dH; pr[0].B[0] = p.Ws; pr[0].A[1] = w.dQ; pr[0].B[1] = p.Wq; pr[0].A[2] = w.dK; pr[0].B[2] = p.Wk;
+        pr[0].A[3] = w.dV; pr[0].B[3] = p.Wv; pr[0].C = dX; pr[0].npairs = 4;
+        if ((rc = launch_gemm(s, GemmShape{(int)N, C, F, F, 1, 1, C, C}, 1, pr, 0, 1, 0.0f, nullptr, nullptr))) return rc;
     }
     return MLLP_OK;
 }
+
+bool feat_ok(int F) { return F == 16 || F == 32 || F == 64 || F == 128 || F == 256; }
 
 }  // namespace
 }  // namespace mllp
@@ -358,8 +644,9 @@ extern "C" int mllp_angle_num_params(int feat_dim, int64_t* out) {
 }
 
 extern "C" int mllp_angle_workspace_floats(int64_t n_nodes, int feat_dim, int64_t* out) {
-    REQUIRE(out && n_nodes >= 2 && feat_dim >= 1, "bad argument");
-    REQUIRE(n_nodes <= 46340, "n_nodes^2 must fit 32-bit GEMM dimensions");
+    REQUIRE(out && n_nodes >= 2, "bad argument");
+    REQUIRE(feat_ok(feat_dim), "AngleModel: feat_dim must be 16, 32, 64, 128 or 256");
+    REQUIRE(n_nodes <= 46340, "n_nodes^2 must fit 32-bit indexing");
     *out = angle_ws_floats(n_nodes, feat_dim);
     return MLLP_OK;
 }
@@ -367,7 +654,8 @@ extern "C" int mllp_angle_workspace_floats(int64_t n_nodes, int feat_dim, int64_
 extern "C" int mllp_angle_forward(int64_t n_nodes, int feat_dim, const float* d_cos, const float* d_x, const float* d_params,
                                   float* d_ws, float* d_logits, void* stream) {
     REQUIRE(d_cos && d_x && d_params && d_ws && d_logits, "null argument");
-    REQUIRE(n_nodes >= 2 && n_nodes <= 46340 && feat_dim >= 1, "bad size");
+    REQUIRE(n_nodes >= 2 && n_nodes <= 46340, "bad size");
+    REQUIRE(feat_ok(feat_dim), "AngleModel: feat_dim must be 16, 32, 64, 128 or 256");
     const int64_t N = n_nodes;
     const int F = feat_dim;
     hipStream_t s = (hipStream_t)stream;
@@ -377,9 +665,9 @@ extern "C" int mllp_angle_forward(int64_t n_nodes, int feat_dim, const float* d_
     const float* fcw = d_params + conv_size(2, F) + 2 * conv_size(F, F);
     int rc;
     // linear_program_methods.py:196-198: gconv1, gconv2, gconv2 (again)
-    if ((rc = conv_forward(s, N, 2, F, d_cos, d_x, p1, w.L[0], w.qe))) return rc;
-    if ((rc = conv_forward(s, N, F, F, d_cos, w.L[0].H, p2, w.L[1], w.qe))) return rc;
-    if ((rc = conv_forward(s, N, F, F, d_cos, w.L[1].H, p2, w.L[2], w.qe))) return rc;
+    if ((rc = conv_forward(s, N, 2, F, d_cos, d_x, p1, w.L[0], w))) return rc;
+    if ((rc = conv_forward(s, N, F, F, d_cos, w.L[0].H, p2, w.L[1], w))) return rc;
+    if ((rc = conv_forward(s, N, F, F, d_cos, w.L[1].H, p2, w.L[2], w))) return rc;
     // :199-200 fc, all nodes but the last
     hipLaunchKernelGGL(fc_kernel, dim3((unsigned)(N - 1)), dim3(AT), 0, s, F, w.L[2].H, fcw, fcw + F, d_logits);
     return check("angle fc");
@@ -388,7 +676,8 @@ extern "C" int mllp_angle_forward(int64_t n_nodes, int feat_dim, const float* d_
 extern "C" int mllp_angle_backward(int64_t n_nodes, int feat_dim, const float* d_cos, const float* d_x, const float* d_params,
                                    float* d_ws, const float* d_dlogits, float* d_grads, void* stream) {
     REQUIRE(d_cos && d_x && d_params && d_ws && d_dlogits && d_grads, "null argument");
-    REQUIRE(n_nodes >= 2 && n_nodes <= 46340 && feat_dim >= 1, "bad size");
+    REQUIRE(n_nodes >= 2 && n_nodes <= 46340, "bad size");
+    REQUIRE(feat_ok(feat_dim), "AngleModel: feat_dim must be 16, 32, 64, 128 or 256");
     const int64_t N = n_nodes;
     const int F = feat_dim;
     hipStream_t s = (hipStream_t)stream;
@@ -400,11 +689,14 @@ extern "C" int mllp_angle_backward(int64_t n_nodes, int feat_dim, const float* d
     const ConvG g2 = conv_at<ConvG>(d_grads + o2, F, F);
     const float* fcw = d_params + ofc;
     int rc;
-    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(AT), 0, s, N, 1.0f, w.ones);
     // gconv3 is never called (reference :198 applies gconv2 twice): its gradient is zero
     MLLP_HIP_TRY(hipMemsetAsync(d_grads + o3, 0, (size_t)conv_size(F, F) * sizeof(float), s));
-    // fc: dW = sum_i dlogit_i H3_i, db = sum_i dlogit_i, dH3 = dlogit w (last node: 0)
-    if ((rc = gemm_rm(s, false, false, 1, F, N - 1, 1.0f, d_dlogits, N - 1, w.L[2].H, F, 0.0f, d_grads + ofc, F))) return rc;
+    {   // fc: dW = sum_i dlogit_i H3_i, db = sum_i dlogit_i, dH3 = dlogit w (last node: 0)
+        GemmProb pr[1] = {};
+        pr[0].A[0] = w.L[2].H; pr[0].B[0] = d_dlogits; pr[0].C = d_grads + ofc; pr[0].npairs = 1;
+        if ((rc = launch_gemm(s, GemmShape{F, 1, (int)(N - 1), 1, F, 1, 1, 1}, 1, pr, 0, std::max(gemm_ksplits(N), 2), 0.0f, w.gpart, nullptr)))
+            return rc;
+    }
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(AT), 0, s, N - 1, d_dlogits, d_grads + ofc + F);
     hipLaunchKernelGGL(fc_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, N - 1, d_dlogits, fcw, w.dA);
     if ((rc = check("angle fc_bwd"))) return rc;

@@ -130,6 +130,35 @@ class _AngleFunction(torch.autograd.Function):
         return grads, None, None
 
 
+class AngleStepper:
+    """The reference's training step for `AngleModel` (linear_program_experiment.py:88-96: BCEWithLogitsLoss, backward,
+    Adam) on FLAT parameters without autograd: forward and backward through the C ABI, the library's Adam kernel
+    (trainer.FlatAdam = torch.optim.Adam's arithmetic).  Same numbers as the module + torch.optim loop (tests), about a
+    dozen small torch kernels fewer per step."""
+
+    def __init__(self, model: "AngleModel", lr=1e-3):
+        from .trainer import FlatAdam
+        self.feat_dim = model.feat_dim
+        self.params = model.flat_parameters().detach().clone().float().contiguous()
+        self.opt = FlatAdam(self.params, lr=lr)
+        self.grads = torch.empty_like(self.params)
+
+    def step(self, g: "AngleGraph", y: torch.Tensor):
+        """One Adam step on graph `g` with labels y [N - 1]; returns (loss [1], logits [N - 1])."""
+        L, N = _lib.lib(), g.num_nodes
+        ws = g.workspace(self.feat_dim)
+        logits = torch.empty(N - 1, dtype=torch.float32, device=self.params.device)
+        _lib.check(L.mllp_angle_forward(N, self.feat_dim, _lib.ptr(g.cos), _lib.ptr(g.x), _lib.ptr(self.params), _lib.ptr(ws),
+                                        _lib.ptr(logits), _lib.current_stream()))
+        g._token += 1
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y)
+        dlogits = (torch.sigmoid(logits) - y) / float(N - 1)             # d mean-BCE / d logits
+        _lib.check(L.mllp_angle_backward(N, self.feat_dim, _lib.ptr(g.cos), _lib.ptr(g.x), _lib.ptr(self.params), _lib.ptr(ws),
+                                         _lib.ptr(dlogits), _lib.ptr(self.grads), _lib.current_stream()))
+        self.opt.step(self.grads)
+        return loss, logits
+
+
 class AngleModel(torch.nn.Module):
     """reference linear_program_methods.py:187-200: gconv1 = TransformerConv(2, F, edge_dim=1), gconv2 and gconv3 =
     TransformerConv(F, F, edge_dim=1), fc = Linear(F, 1); forward applies gconv1, gconv2, gconv2 (gconv3 is never

@@ -13,7 +13,8 @@
 //
 // Round 4: everything is hand-written for the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TFLOP/s peak);
 // rocBLAS is neither linked nor loaded, and no N x N matrix exists in HBM:
-//   * attn_kernel<F, MODE>   one wavefront per (block of 16 "Y" nodes, range of "X" blocks).  Every product is computed
+//   * attn_kernel<F, MODE>   one wavefront per (block of 16 "Y" nodes, range of "X" blocks); four wavefronts share the X
+//       tiles, staged one block ahead into two LDS buffers.  Every product is computed
 //       TRANSPOSED so that no tile ever changes its register layout: T[x][y] = X_x . Y_y lands with y in the lane and x in
 //       the register, which is exactly the B operand of the accumulation  acc[f][y] += W[x][f] T'[x][y].
 //         FWD  X = keys, Y = queries:  T = K Q^T -> online softmax over the X blocks (edge bias (Q . we) A, diagonal
@@ -52,6 +53,17 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return t;
 }
 
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < AT / 64; ++w) t += sh[w];
+    return t;
+}
+
 // =================================================================================================== GEMM
 // C[m][n] = sum over pairs p, k of A_p(m, k) B_p(n, k)  (+ bias[n]),  A_p(m, k) = A_p[m sam + k sak], B_p(n, k) = B_p[n sbn + k sbk]
 struct GemmProb {
@@ -70,8 +82,10 @@ struct GemmBatch {
     int ksplits, kchunk;      // K is cut into ksplits ranges of kchunk (a multiple of 16); > 1: partial sums
     float* partial;           // [problem][ksplit][M][N]
 };
-constexpr int GT = 64, GK = 16, GS = GK + 1;
+constexpr int GT = 64, GK = 32, GS = GK + 1;
 
+// 64 x 64 output tile, K in steps of 32: the 16 elements a thread stages per step are loaded one step ahead (registers),
+// so the L2 latency of a step hides behind the 32 MFMAs per wavefront of the previous one.
 template <bool AK1, bool BK1>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch g) {
     __shared__ float As[GT * GS], Bs[GT * GS];
@@ -81,32 +95,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch g) {
     const int m0 = tm * GT, n0 = tn * GT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int k_lo = blockIdx.y * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
+    const int steps_per_pair = k_hi > k_lo ? (k_hi - k_lo + GK - 1) / GK : 0;
+    const int steps = steps_per_pair * pr.npairs;
     f4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
-    for (int p = 0; p < pr.npairs; ++p) {
+    float ra[8], rb[8];
+    auto fetch = [&](int step) {
+        const int p = step / steps_per_pair, k0 = k_lo + (step % steps_per_pair) * GK;
         const float* __restrict__ A = pr.A[p];
         const float* __restrict__ B = pr.B[p];
-        for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
-            __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int m, k;
-                if (AK1) { m = t >> 2; k = (t & 3) * 4 + i; } else { k = t >> 4; m = (t & 15) * 4 + i; }
-                const bool ok = m0 + m < g.M && k0 + k < k_hi;
-                As[m * GS + k] = ok ? A[(long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak] : 0.0f;
-                int n, kb;
-                if (BK1) { n = t >> 2; kb = (t & 3) * 4 + i; } else { kb = t >> 4; n = (t & 15) * 4 + i; }
-                const bool okb = n0 + n < g.N && k0 + kb < k_hi;
-                float v = 0.0f;
-                if (okb) v = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : B[(long long)(n0 + n) * g.sbn + (long long)(k0 + kb) * g.sbk];
-                Bs[n * GS + kb] = v;
-            }
-            __syncthreads();
+        for (int i = 0; i < 8; ++i) {
+            int m, k;
+            if (AK1) { m = t >> 2; k = (t & 3) * 8 + i; } else { k = t >> 3; m = (t & 7) * 8 + i; }
+            const bool ok = m0 + m < g.M && k0 + k < k_hi;
+            ra[i] = ok ? A[(long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak] : 0.0f;
+            int n, kb;
+            if (BK1) { n = t >> 2; kb = (t & 3) * 8 + i; } else { kb = t >> 3; n = (t & 7) * 8 + i; }
+            const bool okb = n0 + n < g.N && k0 + kb < k_hi;
+            float v = 0.0f;
+            if (okb) v = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : B[(long long)(n0 + n) * g.sbn + (long long)(k0 + kb) * g.sbk];
+            rb[i] = v;
+        }
+    };
+    if (steps > 0) fetch(0);
+    for (int step = 0; step < steps; ++step) {
+        __syncthreads();                    // everybody has left the tiles of the previous step
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float a = As[(16 * w + (lane & 15)) * GS + 4 * kk + (lane >> 4)];
+        for (int i = 0; i < 8; ++i) {
+            int m, k;
+            if (AK1) { m = t >> 2; k = (t & 3) * 8 + i; } else { k = t >> 3; m = (t & 7) * 8 + i; }
+            As[m * GS + k] = ra[i];
+            int n, kb;
+            if (BK1) { n = t >> 2; kb = (t & 3) * 8 + i; } else { kb = t >> 3; n = (t & 7) * 8 + i; }
+            Bs[n * GS + kb] = rb[i];
+        }
+        __syncthreads();
+        if (step + 1 < steps) fetch(step + 1);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4(a, Bs[(16 * nt + (lane & 15)) * GS + 4 * kk + (lane >> 4)], acc[nt]);
-            }
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            const float a = As[(16 * w + (lane & 15)) * GS + 4 * kk + (lane >> 4)];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4(a, Bs[(16 * nt + (lane & 15)) * GS + 4 * kk + (lane >> 4)], acc[nt]);
         }
     }
 #pragma unroll
@@ -145,6 +174,36 @@ int check(const char* what) {
     return e == hipSuccess ? MLLP_OK : hip_fail(e, what);
 }
 
+// out[f] = beta out[f] + sum_k (A1[k][f] b1[k] + A2[k][f] b2[k]): a GEMM with one output column would leave 63 of 64 tile
+// columns empty; chunks of 32 rows, then the same reduction as the split GEMMs
+constexpr int WC_ROWS = 32;
+__global__ __launch_bounds__(AT) void wcolsum_kernel(int K, int F, const float* __restrict__ A1, const float* __restrict__ b1,
+                                                     const float* __restrict__ A2, const float* __restrict__ b2,
+                                                     float* __restrict__ partial) {
+    const int k0 = blockIdx.x * WC_ROWS, k1 = min(K, k0 + WC_ROWS);
+    for (int c = threadIdx.x; c < F; c += AT) {
+        float acc = 0.0f;
+        for (int k = k0; k < k1; k += 8) {          // eight rows of loads in flight
+            float a1[8], a2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = min(k + i, k1 - 1);
+                a1[i] = A1[(size_t)kk * F + c];
+                a2[i] = A2 ? A2[(size_t)kk * F + c] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (k + i < k1) {
+                    acc = fmaf(a1[i], b1[k + i], acc);
+                    if (A2) acc = fmaf(a2[i], b2[k + i], acc);
+                }
+        }
+        partial[(size_t)blockIdx.x * F + c] = acc;
+    }
+}
+int launch_wcolsum(hipStream_t s, int K, int F, const float* A1, const float* b1, const float* A2, const float* b2, float beta,
+                   float* out, float* partial);
+
 // strides of the three forms on row-major operands
 struct GemmShape {
     int M, N, K;
@@ -181,6 +240,16 @@ int launch_gemm(hipStream_t s, const GemmShape& sh, int nprob, const GemmProb* p
     return MLLP_OK;
 }
 
+int launch_wcolsum(hipStream_t s, int K, int F, const float* A1, const float* b1, const float* A2, const float* b2, float beta,
+                   float* out, float* partial) {
+    const int chunks = (K + WC_ROWS - 1) / WC_ROWS;
+    hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)chunks), dim3(AT), 0, s, K, F, A1, b1, A2, b2, partial);
+    ReduceBatch r{};
+    r.C[0] = out; r.M = F; r.N = 1; r.ldc = 1; r.ksplits = chunks; r.ones_col = 0; r.beta = beta; r.partial = partial;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((F + AT - 1) / AT), 1, 1), dim3(AT), 0, s, r);
+    return check("angle wcolsum");
+}
+
 // =================================================================================================== attention
 constexpr int MODE_FWD = 0, MODE_BQ = 1, MODE_BKV = 2;
 struct AttnArgs {
@@ -206,36 +275,45 @@ __device__ __forceinline__ void load_frag(f4 (&fr)[F / 16], const float* __restr
 #pragma unroll
     for (int j = 0; j < F / 16; ++j) fr[j] = row < N ? *reinterpret_cast<const f4*>(p + 16 * j) : f4zero();
 }
+// The 16 rows of an X block live in LDS as a tile of row stride F + 4 floats: both read patterns below are conflict-free.
 // T[x][y] = X_x . Y_y:  lane l, register r  <->  x = 4 (l >> 4) + r,  y = l & 15
 template <int F>
-__device__ __forceinline__ f4 tile_dot(const f4 (&xa)[F / 16], const f4 (&yb)[F / 16]) {
-    f4 t0 = f4zero(), t1 = f4zero();          // two chains: the dependent-accumulator latency (40) exceeds the issue time (32)
+__device__ __forceinline__ f4 tile_dot(const float* __restrict__ tile, const f4 (&yb)[F / 16], int lane) {
+    const float* p = tile + (lane & 15) * (F + 4) + 4 * (lane >> 4);
+    // four independent chains: with two, a dependent MFMA issued every ~53 cycles instead of 32 (measured: the dot
+    // products ran at 0.6 of the rate of the 16-chain accumulation)
+    f4 t0 = f4zero(), t1 = f4zero(), t2 = f4zero(), t3 = f4zero();
 #pragma unroll
     for (int j = 0; j < F / 16; ++j) {
-        t0 = mfma4(xa[j][0], yb[j][0], t0);
-        t1 = mfma4(xa[j][1], yb[j][1], t1);
-        t0 = mfma4(xa[j][2], yb[j][2], t0);
-        t1 = mfma4(xa[j][3], yb[j][3], t1);
+        const f4 xa = *reinterpret_cast<const f4*>(p + 16 * j);
+        t0 = mfma4(xa[0], yb[j][0], t0);
+        t1 = mfma4(xa[1], yb[j][1], t1);
+        t2 = mfma4(xa[2], yb[j][2], t2);
+        t3 = mfma4(xa[3], yb[j][3], t3);
     }
-    return t0 + t1;
+    return (t0 + t1) + (t2 + t3);
 }
-// acc[f][y] += sum_x W[x][f] t[x][y]:  MFMA r takes x = x0 + 4 (l >> 4) + r as its k slot; the A operand of lane (g, i) is
-// W[x][64 u + 4 i + c] (one 16-byte load gives c = 0..3, i.e. the four tiles (u, c)); tile (u, c), register rr of lane (g, y)
+// acc[f][y] += sum_x W[x][f] t[x][y]:  MFMA r takes x = 4 (l >> 4) + r as its k slot; the A operand of lane (g, i) is
+// W[x][64 u + 4 i + c] (one 16-byte read gives c = 0..3, i.e. the four tiles (u, c)); tile (u, c), register rr of lane (g, y)
 // then holds f = 64 u + 16 g + 4 rr + c.
 template <int F>
-__device__ __forceinline__ void accumulate(f4 (&acc)[(F + 63) / 64 * 4], const float* __restrict__ W, int x0, int N, int lane, const f4& t) {
+__device__ __forceinline__ void accumulate(f4 (&acc)[(F + 63) / 64 * 4], const float* __restrict__ tile, int lane, const f4& t) {
     constexpr int FU = (F + 63) / 64;
     const int i4 = 4 * (lane & 15);
+    f4 w[2][FU];                               // the reads of k slot r + 1 are in flight while slot r multiplies
+    auto rd = [&](int r, f4 (&d)[FU]) {
+        const float* p = tile + (4 * (lane >> 4) + r) * (F + 4) + i4;
+#pragma unroll
+        for (int u = 0; u < FU; ++u) d[u] = 64 * u + i4 < F ? *reinterpret_cast<const f4*>(p + 64 * u) : f4zero();
+    };
+    rd(0, w[0]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int x = x0 + 4 * (lane >> 4) + r;
-        const float* p = W + (size_t)x * F + i4;
+        if (r < 3) rd(r + 1, w[(r + 1) & 1]);
 #pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const f4 w = (x < N && 64 * u + i4 < F) ? *reinterpret_cast<const f4*>(p + 64 * u) : f4zero();
+        for (int u = 0; u < FU; ++u)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[4 * u + c] = mfma4(w[c], t[r], acc[4 * u + c]);
-        }
+            for (int c = 0; c < 4; ++c) acc[4 * u + c] = mfma4(w[r & 1][u][c], t[r], acc[4 * u + c]);
     }
 }
 template <int F>
@@ -259,16 +337,67 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+constexpr int ATT_W = 4;                  // wavefronts (= Y blocks of 16 nodes) per workgroup: they share the X tiles
+#ifndef MLLP_ANGLE_ABL                    // timing experiments only (tools/variant_lib.sh): 1 no dot products, 2 no accumulation,
+#define MLLP_ANGLE_ABL 0                  // 4 no softmax arithmetic, 8 no staging of the next tiles
+#endif
+constexpr int AABL = MLLP_ANGLE_ABL;
+
+// One workgroup = 4 wavefronts = 64 Y nodes, one range of X blocks.  The two matrices of an X block (FWD: K, V; BQ: K, V;
+// BKV: Q, dO -- each serves as the operand of a dot product AND of an accumulation) are staged global -> registers -> LDS
+// one block ahead (two buffers, one barrier per block).
 template <int F, int MODE>
-__global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
-    constexpr int FJ = F / 16, NA = (F + 63) / 64 * 4;
-    const int lane = threadIdx.x, g = lane >> 4;
+__global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
+    constexpr int FJ = F / 16, NA = (F + 63) / 64 * 4, RS = F + 4, TILE = 16 * RS;
+    constexpr int NLD = (16 * F / 4 + 64 * ATT_W - 1) / (64 * ATT_W);       // 16-byte pieces of a tile per thread
+    __shared__ __attribute__((aligned(16))) float sm[2][2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4;
     const int N = a.N;
-    const int y0 = blockIdx.x * 16, y = y0 + (lane & 15);
+    const int y0 = (blockIdx.x * ATT_W + wv) * 16, y = y0 + (lane & 15);
     const int n_xb = (N + 15) / 16;
     const int xb_lo = blockIdx.y * a.xb_per_range, xb_hi = min(n_xb, xb_lo + a.xb_per_range);
     const bool yok = y < N;
     const float* __restrict__ cosrow = a.cos + (size_t)min(y, N - 1) * N;
+    const float* __restrict__ XA = a.X1;
+    const float* __restrict__ XB = MODE == MODE_FWD ? a.W1 : a.X2;
+
+    f4 pa[NLD], pb[NLD];
+    auto fetch = [&](int xb) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 64 * ATT_W * i, row = e / (F / 4), c4 = e % (F / 4);
+            // (no branch: a clamped address, then a select; rows behind N are zero in the tile)
+            const bool ok = e < 16 * F / 4 && xb * 16 + row < N;
+            const size_t off = (size_t)min(xb * 16 + min(row, 15), N - 1) * F + 4 * c4;
+            const f4 va = *reinterpret_cast<const f4*>(XA + off), vb = *reinterpret_cast<const f4*>(XB + off);
+            pa[i] = ok ? va : f4zero();
+            pb[i] = ok ? vb : f4zero();
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 64 * ATT_W * i, row = e / (F / 4), c4 = e % (F / 4);
+            if (e < 16 * F / 4) {
+                *reinterpret_cast<f4*>(&sm[buf][0][row * RS + 4 * c4]) = pa[i];
+                *reinterpret_cast<f4*>(&sm[buf][1][row * RS + 4 * c4]) = pb[i];
+            }
+        }
+    };
+    // the edge attributes of the block (and, BKV, the scalars of its X nodes) also come one block ahead
+    float ncv[4], nst[MODE == MODE_BKV ? 20 : 1];
+    auto fetch_small = [&](int xb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = xb * 16 + 4 * g + r;
+            ncv[r] = (yok && x < N) ? cosrow[x] : 0.0f;      // (the matrix is symmetric: A[y][x] serves both orientations)
+            if constexpr (MODE == MODE_BKV) {
+                const int xc = min(x, N - 1);
+                nst[r] = a.qe[xc]; nst[4 + r] = a.m[xc]; nst[8 + r] = a.inv[xc]; nst[12 + r] = a.u[xc]; nst[16 + r] = a.D[xc];
+            }
+        }
+    };
+    if (xb_lo < xb_hi) { fetch(xb_lo); fetch_small(xb_lo); }
 
     f4 y1[FJ], y2[MODE == MODE_FWD ? 1 : FJ];
     load_frag<F>(y1, a.Y1, y0, N, lane);
@@ -287,8 +416,8 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
         const float* wp = a.we + 4 * g;
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
-            const f4 wv = *reinterpret_cast<const f4*>(wp + 16 * j);
-            d = fmaf(y1[j][0], wv[0], d); d = fmaf(y1[j][1], wv[1], d); d = fmaf(y1[j][2], wv[2], d); d = fmaf(y1[j][3], wv[3], d);
+            const f4 wv4 = *reinterpret_cast<const f4*>(wp + 16 * j);
+            d = fmaf(y1[j][0], wv4[0], d); d = fmaf(y1[j][1], wv4[1], d); d = fmaf(y1[j][2], wv4[2], d); d = fmaf(y1[j][3], wv4[3], d);
         }
         qe_y = group_sum(d);
         if (blockIdx.y == 0 && g == 0 && yok) a.qe_out[y] = qe_y;
@@ -296,24 +425,29 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
         if (yok) { qe_y = a.qe[y]; m_y = a.m[y]; inv_y = a.inv[y]; u_y = a.u[y]; D_y = a.D[y]; }
     }
     float run_m = NEG_BIG, run_l = 0.f, run_u = 0.f, run_r = 0.f;
+    if (xb_lo < xb_hi) stage(0);
+    __syncthreads();
 
     for (int xb = xb_lo; xb < xb_hi; ++xb) {
+        const int buf = (xb - xb_lo) & 1;
+        const float* tA = sm[buf][0];
+        const float* tB = sm[buf][1];
+        float cv[4], st[MODE == MODE_BKV ? 20 : 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[r] = ncv[r];
+        if constexpr (MODE == MODE_BKV)
+#pragma unroll
+            for (int r = 0; r < 20; ++r) st[r] = nst[r];
+        if (xb + 1 < xb_hi && !(AABL & 8)) { fetch(xb + 1); fetch_small(xb + 1); }
         const int x0 = xb * 16, xg = x0 + 4 * g;
-        f4 xa[FJ];
-        load_frag<F>(xa, a.X1, x0, N, lane);
-        f4 t1 = tile_dot<F>(xa, y1);
+        f4 t1 = (AABL & 1) ? f4{cv[0], cv[1], cv[2], cv[3]} : tile_dot<F>(tA, y1, lane);
         f4 t2 = f4zero();
-        if constexpr (MODE != MODE_FWD) {
-            load_frag<F>(xa, a.X2, x0, N, lane);
-            t2 = tile_dot<F>(xa, y2);
-        }
-        float cv[4];
+        if constexpr (MODE != MODE_FWD) t2 = (AABL & 1) ? t1 : tile_dot<F>(tB, y2, lane);
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int x = xg + r;
             ok[r] = yok && x < N && x != y;
-            cv[r] = (yok && x < N) ? cosrow[x] : 0.0f;        // (the matrix is symmetric: A[y][x] serves both orientations)
         }
         if constexpr (MODE == MODE_FWD) {
             float L[4], lm = NEG_BIG;
@@ -322,50 +456,53 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs a) {
                 L[r] = ok[r] ? fmaf(qe_y, cv[r], t1[r]) * a.scale : NEG_BIG;
                 lm = fmaxf(lm, L[r]);
             }
-            lm = group_max(lm);
-            const float mn = fmaxf(run_m, lm);
+            if (!(AABL & 4)) lm = group_max(lm);
+            // the reference of the running sums moves only when a logit exceeds it by more than 8 (p <= e^8 is harmless in
+            // fp32 and alpha = p / l does not depend on the reference): the accumulators are rescaled a few times per range
+            const float mn = lm > run_m + 8.0f ? lm : run_m;
             const float al = exp_acc(run_m - mn);
             run_m = mn;
             f4 p;
             float ps = 0.f, pu = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = ok[r] ? exp_acc(L[r] - mn) : 0.0f;
+                p[r] = (AABL & 4) ? L[r] : (ok[r] ? exp_acc(L[r] - mn) : 0.0f);
                 ps += p[r];
                 pu = fmaf(p[r], cv[r], pu);
             }
             run_l = fmaf(run_l, al, ps);
             run_u = fmaf(run_u, al, pu);
-            if (__any(al != 1.0f)) {
+            if (__builtin_expect(__any(al != 1.0f), 0)) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) acc1[i] *= al;
             }
-            accumulate<F>(acc1, a.W1, x0, N, lane, p);
+            if (!(AABL & 2)) accumulate<F>(acc1, tB, lane, p);
+            else acc1[0] += p;
         } else {
             float qe_[4], m_[4], inv_[4], u_[4], D_[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (MODE == MODE_BQ) { qe_[r] = qe_y; m_[r] = m_y; inv_[r] = inv_y; u_[r] = u_y; D_[r] = D_y; }
-                else {
-                    const int x = min(xg + r, N - 1);
-                    qe_[r] = a.qe[x]; m_[r] = a.m[x]; inv_[r] = a.inv[x]; u_[r] = a.u[x]; D_[r] = a.D[x];
-                }
+                else { qe_[r] = st[r]; m_[r] = st[4 + r]; inv_[r] = st[8 + r]; u_[r] = st[12 + r]; D_[r] = st[16 + r]; }
             }
             f4 p, dz;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float L = fmaf(qe_[r], cv[r], t1[r]) * a.scale;
-                p[r] = ok[r] ? exp_acc(L - m_[r]) * inv_[r] : 0.0f;
+                p[r] = (AABL & 4) ? L : (ok[r] ? exp_acc(L - m_[r]) * inv_[r] : 0.0f);
                 const float dp = fmaf(u_[r], cv[r], t2[r]);
                 dz[r] = p[r] * (dp - D_[r]) * a.scale;
                 run_r = fmaf(dz[r], cv[r], run_r);
             }
-            if constexpr (MODE == MODE_BQ) accumulate<F>(acc1, a.W1, x0, N, lane, dz);
+            if (AABL & 2) { acc1[0] += dz; acc1[1] += p; }
+            else if constexpr (MODE == MODE_BQ) accumulate<F>(acc1, tA, lane, dz);      // dQ += K^T dz
             else {
-                accumulate<F>(acc1, a.W1, x0, N, lane, p);
-                accumulate<F>(acc2, a.W2, x0, N, lane, dz);
+                accumulate<F>(acc1, tB, lane, p);                                   // dV += dO^T p
+                accumulate<F>(acc2, tA, lane, dz);                                  // dK += Q^T dz
             }
         }
+        if (xb + 1 < xb_hi && !(AABL & 8)) stage(buf ^ 1);
+        __syncthreads();
     }
     const size_t slab = (size_t)blockIdx.y * N;
     store_acc<F>(acc1, a.part1 + slab * F, y, N, lane);
@@ -408,11 +545,13 @@ __global__ __launch_bounds__(AT) void fwd_combine_kernel(int N, int F, int range
     }
 }
 
-// out[i][:] = sum over the ranges of part (+ r_i w, r_i = sum over the ranges of stats)
+// out[i][:] = sum over the ranges of part (+ r_i w, r_i = sum over the ranges of stats); blockIdx.y = 1: the second pair
 __global__ __launch_bounds__(AT) void sum_ranges_kernel(int N, int F, int ranges, const float* __restrict__ part,
                                                         const float* __restrict__ stats, const float* __restrict__ w,
-                                                        float* __restrict__ out, float* __restrict__ r_out) {
+                                                        float* __restrict__ out, float* __restrict__ r_out,
+                                                        const float* __restrict__ part_b, float* __restrict__ out_b) {
     const int i = blockIdx.x;
+    if (blockIdx.y == 1) { part = part_b; out = out_b; }
     float r = 0.f;
     if (stats) {
         for (int s = 0; s < ranges; ++s) r += stats[((size_t)s * N + i) * 4];
@@ -429,20 +568,22 @@ __global__ __launch_bounds__(AT) void sum_ranges_kernel(int N, int F, int ranges
 __global__ __launch_bounds__(AT) void relu_bwd_kernel(int F, float* __restrict__ dH, const float* __restrict__ H,
                                                       const float* __restrict__ Oa, const float* __restrict__ we,
                                                       const float* __restrict__ s, float* __restrict__ u, float* __restrict__ D) {
-    __shared__ float sh[AT / 64];
+    __shared__ double shd[AT / 64];
     float* row = dH + (size_t)blockIdx.x * F;
     const float* h = H + (size_t)blockIdx.x * F;
     const float* oa = Oa + (size_t)blockIdx.x * F;
-    float au = 0.0f, ad = 0.0f;
+    // (D in double: the dz of a row must sum to zero, and they do only as far as D equals sum_j p_ij dp_ij -- the key
+    // gradients are what is left of that cancellation)
+    double au = 0.0, ad = 0.0;
     for (int c = threadIdx.x; c < F; c += AT) {
         const float v = h[c] > 0.0f ? row[c] : 0.0f;
         row[c] = v;
-        au = fmaf(v, we[c], au);
-        ad = fmaf(v, oa[c], ad);
+        au += (double)v * (double)we[c];
+        ad += (double)v * (double)oa[c];
     }
-    const float tu = block_sum(au, sh);
-    const float td = block_sum(ad, sh);
-    if (threadIdx.x == 0) { u[blockIdx.x] = tu; D[blockIdx.x] = fmaf(tu, s[blockIdx.x], td); }
+    const double tu = block_sum_d(au, shd);
+    const double td = block_sum_d(ad, shd);
+    if (threadIdx.x == 0) { u[blockIdx.x] = (float)tu; D[blockIdx.x] = (float)(tu * (double)s[blockIdx.x] + td); }
 }
 
 // logits[i] = H[i, :] . w + b  for i < n_out
@@ -491,11 +632,11 @@ P conv_at(T* base, int C, int F) {
     return p;
 }
 
-// ranges of X blocks per Y block: enough wavefronts for every SIMD of the chip (one wavefront per SIMD: the kernels hold
-// up to ~350 registers), never more ranges than X blocks, at most 32
+// ranges of X blocks per group of 64 Y nodes: ONE workgroup per CU (the kernels hold 340-500 registers, and the ~10 us
+// a workgroup spends before its first and after its last block are paid once), never more ranges than X blocks, at most 32
 int attn_ranges(int64_t N) {
-    const int64_t nb = (N + 15) / 16;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 32), (2048 + nb - 1) / nb));
+    const int64_t nb = (N + 15) / 16, yg = (nb + ATT_W - 1) / ATT_W;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 32), 256 / std::min<int64_t>(yg, 256)));
 }
 int gemm_ksplits(int64_t K) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, K / 128)); }
 
@@ -538,13 +679,14 @@ AngleWs angle_carve(float* base, int64_t N, int F) {
 
 template <int MODE>
 int launch_attn(hipStream_t s, int F, const AttnArgs& a) {
-    const dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)(((a.N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range));
+    const int nb = (a.N + 15) / 16;
+    const dim3 grid((unsigned)((nb + ATT_W - 1) / ATT_W), (unsigned)((nb + a.xb_per_range - 1) / a.xb_per_range)), block(64 * ATT_W);
     switch (F) {
-        case 16: hipLaunchKernelGGL((attn_kernel<16, MODE>), grid, dim3(64), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((attn_kernel<32, MODE>), grid, dim3(64), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((attn_kernel<64, MODE>), grid, dim3(64), 0, s, a); break;
-        case 128: hipLaunchKernelGGL((attn_kernel<128, MODE>), grid, dim3(64), 0, s, a); break;
-        case 256: hipLaunchKernelGGL((attn_kernel<256, MODE>), grid, dim3(64), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((attn_kernel<16, MODE>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((attn_kernel<32, MODE>), grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL((attn_kernel<64, MODE>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((attn_kernel<128, MODE>), grid, block, 0, s, a); break;
+        case 256: hipLaunchKernelGGL((attn_kernel<256, MODE>), grid, block, 0, s, a); break;
         default: return fail(MLLP_EINVAL, "AngleModel: feat_dim must be 16, 32, 64, 128 or 256");
     }
     return check("angle attention");
@@ -593,14 +735,13 @@ int conv_backward(hipStream_t s, int64_t N, int C, int F, const float* A, const 
     // dQ = dz K + r we^T,  r = sum dz A
     a.Y1 = L.Q; a.Y2 = dH; a.X1 = L.K; a.X2 = L.V; a.W1 = L.K;
     if ((rc = launch_attn<MODE_BQ>(s, F, a))) return rc;
-    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, w.stats, p.we, w.dQ, w.r);
+    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, w.stats, p.we, w.dQ, w.r,
+                       (const float*)nullptr, (float*)nullptr);
     // dV = alpha^T dO,  dK = dz^T Q
     a.Y1 = L.K; a.Y2 = L.V; a.X1 = L.Q; a.X2 = dH; a.W1 = dH; a.W2 = L.Q;
     if ((rc = launch_attn<MODE_BKV>(s, F, a))) return rc;
-    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part1, (const float*)nullptr,
-                       (const float*)nullptr, w.dV, (float*)nullptr);
-    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N), dim3(AT), 0, s, (int)N, F, ranges, w.part2, (const float*)nullptr,
-                       (const float*)nullptr, w.dK, (float*)nullptr);
+    hipLaunchKernelGGL(sum_ranges_kernel, dim3((unsigned)N, 2), dim3(AT), 0, s, (int)N, F, ranges, w.part1, (const float*)nullptr,
+                       (const float*)nullptr, w.dV, (float*)nullptr, w.part2, w.dK);
     if ((rc = check("angle sum_ranges"))) return rc;
     const int ks = gemm_ksplits(N);
     {   // dW = dY^T X and db = 1^T dY of the four projections in one launch (K = N, split; the ones column gives db)
@@ -611,16 +752,14 @@ int conv_backward(hipStream_t s, int64_t N, int C, int F, const float* A, const 
         for (int i = 0; i < 4; ++i) { pr[i].A[0] = dY[i]; pr[i].B[0] = X; pr[i].C = dW[i]; pr[i].npairs = 1; }
         if ((rc = launch_gemm(s, GemmShape{F, C + 1, (int)N, 1, F, 1, C, C}, 4, pr, 1, ks, beta, w.gpart, db))) return rc;
     }
-    {   // dwe = dO^T s + Q^T r
-        GemmProb pr[1] = {};
-        pr[0].A[0] = dH; pr[0].B[0] = L.s; pr[0].A[1] = L.Q; pr[0].B[1] = w.r; pr[0].C = g.we; pr[0].npairs = 2;
-        if ((rc = launch_gemm(s, GemmShape{F, 1, (int)N, 1, F, 1, 1, 1}, 1, pr, 0, std::max(ks, 2), beta, w.gpart, nullptr))) return rc;
-    }
+    if ((rc = launch_wcolsum(s, (int)N, F, dH, L.s, L.Q, w.r, beta, g.we, w.gpart))) return rc;       // dwe = dO^T s + Q^T r
     if (dX) {   // dX = dO Ws + dQ Wq + dK Wk + dV Wv
         GemmProb pr[1] = {};
         pr[0].A[0] = dH; pr[0].B[0] = p.Ws; pr[0].A[1] = w.dQ; pr[0].B[1] = p.Wq; pr[0].A[2] = w.dK; pr[0].B[2] = p.Wk;
         pr[0].A[3] = w.dV; pr[0].B[3] = p.Wv; pr[0].C = dX; pr[0].npairs = 4;
-        if ((rc = launch_gemm(s, GemmShape{(int)N, C, F, F, 1, 1, C, C}, 1, pr, 0, 1, 0.0f, nullptr, nullptr))) return rc;
+        // (few output tiles: the feature range of every pair is cut in up to four, partial sums in the idle range buffer)
+        const int ksx = std::min(std::min(4, attn_ranges(N)), std::max(1, F / 32));
+        if ((rc = launch_gemm(s, GemmShape{(int)N, C, F, F, 1, 1, C, C}, 1, pr, 0, ksx, 0.0f, w.part1, nullptr))) return rc;
     }
     return MLLP_OK;
 }
@@ -691,12 +830,8 @@ extern "C" int mllp_angle_backward(int64_t n_nodes, int feat_dim, const float* d
     int rc;
     // gconv3 is never called (reference :198 applies gconv2 twice): its gradient is zero
     MLLP_HIP_TRY(hipMemsetAsync(d_grads + o3, 0, (size_t)conv_size(F, F) * sizeof(float), s));
-    {   // fc: dW = sum_i dlogit_i H3_i, db = sum_i dlogit_i, dH3 = dlogit w (last node: 0)
-        GemmProb pr[1] = {};
-        pr[0].A[0] = w.L[2].H; pr[0].B[0] = d_dlogits; pr[0].C = d_grads + ofc; pr[0].npairs = 1;
-        if ((rc = launch_gemm(s, GemmShape{F, 1, (int)(N - 1), 1, F, 1, 1, 1}, 1, pr, 0, std::max(gemm_ksplits(N), 2), 0.0f, w.gpart, nullptr)))
-            return rc;
-    }
+    // fc: dW = sum_i dlogit_i H3_i, db = sum_i dlogit_i, dH3 = dlogit w (last node: 0)
+    if ((rc = launch_wcolsum(s, (int)(N - 1), F, w.L[2].H, d_dlogits, nullptr, nullptr, 0.0f, d_grads + ofc, w.gpart))) return rc;
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(AT), 0, s, N - 1, d_dlogits, d_grads + ofc + F);
     hipLaunchKernelGGL(fc_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, N - 1, d_dlogits, fcw, w.dA);
     if ((rc = check("angle fc_bwd"))) return rc;

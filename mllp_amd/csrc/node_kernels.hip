@@ -495,8 +495,24 @@ __global__ __launch_bounds__(1024) void adam_kernel(float* __restrict__ p, const
     adam_body(p, g, m, v, state, eps, gscale, n);
 }
 
+// many parameters (AngleModel at feat_dim 256: 529 k): slices of 4096 elements per workgroup; the workgroups only READ the
+// step counter, a one-thread launch behind them advances it (stream order; capturable like the single launch)
+constexpr int ADAM_SLICE = 4096;
+__global__ __launch_bounds__(1024) void adam_wide_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ state, float eps, float gscale, int n) {
+    const int o = blockIdx.x * ADAM_SLICE;
+    adam_slice(p + o, g + o, m + o, v + o, state[0] + 1.0f, state[1], state[2], state[3], eps, gscale, min(ADAM_SLICE, n - o));
+}
+__global__ void adam_tick_kernel(float* __restrict__ state) { state[0] += 1.0f; }
+
 int launch_adam(float* p, const float* g, float* m, float* v, float* state, float eps, float gscale, int64_t n,
                 hipStream_t s) {
+    if (n > 4 * ADAM_SLICE) {
+        hipLaunchKernelGGL(adam_wide_kernel, dim3((unsigned)((n + ADAM_SLICE - 1) / ADAM_SLICE)), dim3(1024), 0, s, p, g, m, v, state,
+                           eps, gscale, (int)n);
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, state);
+    } else
     hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(1024), 0, s, p, g, m, v, state, eps, gscale, (int)n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MLLP_OK : hip_fail(e, "adam");

@@ -116,3 +116,37 @@ def test_angle_driver_end_to_end(tmp_path, monkeypatch, capsys):
     sd = torch.load(tmp_path / "linear_program_netlib_angleNet.pt", weights_only=True)
     assert sd["gconv1.lin_key.weight"].shape == (32, 2) and sd["gconv2.lin_edge.weight"].shape == (32, 1)
     assert sd["fc.weight"].shape == (1, 32) and any(s.startswith("epoch 2, obj=") for s in lines)
+
+
+@pytest.mark.gpu
+def test_angle_stepper_equals_module_loop():
+    """AngleStepper (flat parameters, C ABI forward / backward, the library's Adam kernel) follows the nn.Module +
+    autograd + torch.optim.Adam loop of the reference (linear_program_experiment.py:88-96) step for step; feat_dim
+    outside {16, 32, 64, 128, 256} is refused loudly."""
+    from mllp_amd import _lib
+    from mllp_amd.angle import AngleModel, AngleStepper, build_graph_from_Q_sets
+    from mllp_amd.model import set_seed
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((150, 30)))
+    coefs = rng.standard_normal(150)
+    basis = (rng.random(149) < 0.3).astype(np.int32)
+    g = build_graph_from_Q_sets(Q, coefs, torch.device("cuda"), "stepper", basis)
+    assert torch.equal(g.cos, g.cos.T)
+    y = torch.tensor(basis, dtype=torch.float, device="cuda")
+    set_seed(3)
+    model = AngleModel(feat_dim=32).to("cuda")
+    st = AngleStepper(model, lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.BCEWithLogitsLoss()
+    for _ in range(4):
+        opt.zero_grad()
+        loss = crit(model(g), y)
+        loss.backward()
+        opt.step()
+        loss2, _ = st.step(g, y)
+        assert abs(float(loss) - float(loss2)) <= 2e-6 * abs(float(loss))
+    a, b = model.flat_parameters().detach(), st.params
+    keep = (a - b).abs() <= 2e-5 * a.abs().max()
+    assert bool(keep.all())
+    with pytest.raises(_lib.MllpError, match="feat_dim"):
+        AngleModel(feat_dim=24).to("cuda")(g)

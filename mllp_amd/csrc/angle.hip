@@ -150,6 +150,91 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch g) {
         }
 }
 
+// The same tile with 16-byte global loads (every operand's contiguous dimension is a multiple of 4 elements from an aligned
+// base: the F x F layers), 32-bit offsets and a row stride of 36 floats in LDS (16-byte aligned rows, conflict-free MFMA
+// operand reads): a quarter of the load / address instructions of the scalar kernel, which stays for the 2-column layer.
+constexpr int GV = 36;
+template <bool AK1, bool BK1>
+__global__ __launch_bounds__(256) void gemm_vec_kernel(GemmBatch g) {
+    __shared__ __attribute__((aligned(16))) float As[GT * GV], Bs[GT * GV];
+    const GemmProb& pr = g.p[blockIdx.z];
+    const int tiles_n = (g.N + GT - 1) / GT;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int k_lo = blockIdx.y * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
+    const int steps_per_pair = k_hi > k_lo ? (k_hi - k_lo + GK - 1) / GK : 0;
+    const int steps = steps_per_pair * pr.npairs;
+    const int sam = (int)g.sam, sak = (int)g.sak, sbn = (int)g.sbn, sbk = (int)g.sbk;
+    f4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
+    f4 ra[2], rb[2];
+    // one 16-byte piece: K1: elements (r, k .. k + 3) of P[r sr + k]; else elements (r .. r + 3, k) of P[k sk + r]
+    auto piece = [&](const float* __restrict__ P, bool k1, int r, int R, int k, int sr, int sk, bool ones) -> f4 {
+        if (k1) {
+            if (r < R && k + 3 < k_hi && !(ones && r == R - 1)) return *reinterpret_cast<const f4*>(P + r * sr + k);
+            f4 v = f4zero();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r < R && k + j < k_hi) v[j] = (ones && r == R - 1) ? 1.0f : P[r * sr + k + j];
+            return v;
+        }
+        if (k < k_hi && r + 3 < R - (ones ? 1 : 0)) return *reinterpret_cast<const f4*>(P + k * sk + r);
+        f4 v = f4zero();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k < k_hi && r + j < R) v[j] = (ones && r + j == R - 1) ? 1.0f : P[k * sk + r + j];
+        return v;
+    };
+    auto fetch = [&](int step) {
+        const int p = step / steps_per_pair, k0 = k_lo + (step % steps_per_pair) * GK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + 256 * i;
+            if (AK1) ra[i] = piece(pr.A[p], true, m0 + (idx >> 3), g.M, k0 + 4 * (idx & 7), sam, 1, false);
+            else ra[i] = piece(pr.A[p], false, m0 + 4 * (idx & 15), g.M, k0 + (idx >> 4), 1, sak, false);
+            if (BK1) rb[i] = piece(pr.B[p], true, n0 + (idx >> 3), g.N, k0 + 4 * (idx & 7), sbn, 1, g.ones_col != 0);
+            else rb[i] = piece(pr.B[p], false, n0 + 4 * (idx & 15), g.N, k0 + (idx >> 4), 1, sbk, g.ones_col != 0);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + 256 * i;
+            if (AK1) *reinterpret_cast<f4*>(&As[(idx >> 3) * GV + 4 * (idx & 7)]) = ra[i];
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * (idx & 15) + j) * GV + (idx >> 4)] = ra[i][j];
+            if (BK1) *reinterpret_cast<f4*>(&Bs[(idx >> 3) * GV + 4 * (idx & 7)]) = rb[i];
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * (idx & 15) + j) * GV + (idx >> 4)] = rb[i][j];
+        }
+    };
+    if (steps > 0) fetch(0);
+    for (int step = 0; step < steps; ++step) {
+        __syncthreads();                    // everybody has left the tiles of the previous step
+        stage();
+        __syncthreads();
+        if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            const float a = As[(16 * w + (lane & 15)) * GV + 4 * kk + (lane >> 4)];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma4(a, Bs[(16 * nt + (lane & 15)) * GV + 4 * kk + (lane >> 4)], acc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * w + 4 * (lane >> 4) + r, n = n0 + 16 * nt + (lane & 15);
+            if (m < g.M && n < g.N) {
+                if (g.ksplits == 1 && !g.ones_col) pr.C[(long long)m * g.ldc + n] = acc[nt][r] + (pr.bias ? pr.bias[n] : 0.0f);
+                else g.partial[(((long long)blockIdx.z * g.ksplits + blockIdx.y) * g.M + m) * g.N + n] = acc[nt][r];
+            }
+        }
+}
+
 // C[m][n] = beta C[m][n] + sum over the K ranges; with a ones column: column N - 1 goes to colsum[m] instead
 struct ReduceBatch {
     float* C[4];
@@ -222,7 +307,16 @@ int launch_gemm(hipStream_t s, const GemmShape& sh, int nprob, const GemmProb* p
     g.partial = partial;
     const dim3 grid((unsigned)(((sh.M + GT - 1) / GT) * ((sh.N + GT - 1) / GT)), (unsigned)ksplits, (unsigned)nprob);
     const bool ak1 = sh.sak == 1, bk1 = sh.sbk == 1;
-    if (ak1 && bk1) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+    bool vec = (ak1 ? sh.sam : sh.sak) % 4 == 0 && (bk1 ? sh.sbn : sh.sbk) % 4 == 0 && (long long)sh.M * std::max(sh.sam, sh.sak) < (1ll << 31);
+    for (int i = 0; i < nprob && vec; ++i)
+        for (int q = 0; q < probs[i].npairs; ++q)
+            vec = vec && (reinterpret_cast<uintptr_t>(probs[i].A[q]) & 15) == 0 && (reinterpret_cast<uintptr_t>(probs[i].B[q]) & 15) == 0;
+    if (vec) {
+        if (ak1 && bk1) hipLaunchKernelGGL((gemm_vec_kernel<true, true>), grid, dim3(256), 0, s, g);
+        else if (ak1) hipLaunchKernelGGL((gemm_vec_kernel<true, false>), grid, dim3(256), 0, s, g);
+        else if (bk1) hipLaunchKernelGGL((gemm_vec_kernel<false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_vec_kernel<false, false>), grid, dim3(256), 0, s, g);
+    } else if (ak1 && bk1) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
     else if (ak1) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
     else if (bk1) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
@@ -344,12 +438,11 @@ constexpr int ATT_W = 4;                  // wavefronts (= Y blocks of 16 nodes)
 constexpr int AABL = MLLP_ANGLE_ABL;
 
 // One workgroup = 4 wavefronts = 64 Y nodes, one range of X blocks.  The two matrices of an X block (FWD: K, V; BQ: K, V;
-// BKV: Q, dO -- each serves as the operand of a dot product AND of an accumulation) are staged global -> registers -> LDS
-// one block ahead (two buffers, one barrier per block).
+// BKV: Q, dO -- each serves as the operand of a dot product AND of an accumulation) are staged by LDS-DMA one block ahead
+// (two buffers, one barrier per block).
 template <int F, int MODE>
-__global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_kernel(AttnArgs a) {
     constexpr int FJ = F / 16, NA = (F + 63) / 64 * 4, RS = F + 4, TILE = 16 * RS;
-    constexpr int NLD = (16 * F / 4 + 64 * ATT_W - 1) / (64 * ATT_W);       // 16-byte pieces of a tile per thread
     __shared__ __attribute__((aligned(16))) float sm[2][2][TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4;
     const int N = a.N;
@@ -361,26 +454,19 @@ __global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
     const float* __restrict__ XA = a.X1;
     const float* __restrict__ XB = MODE == MODE_FWD ? a.W1 : a.X2;
 
-    f4 pa[NLD], pb[NLD];
-    auto fetch = [&](int xb) {
+    // LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no registers, no ds_write): one instruction
+    // copies one row of a tile (F / 4 lanes), wavefront w the rows w, w + 4, ...  A row behind N is row N - 1 again: finite
+    // data whose products are masked (p = dz = 0 for x >= N).
+    auto fetch = [&](int xb, int buf) {
+        if (lane < F / 4) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 64 * ATT_W * i, row = e / (F / 4), c4 = e % (F / 4);
-            // (no branch: a clamped address, then a select; rows behind N are zero in the tile)
-            const bool ok = e < 16 * F / 4 && xb * 16 + row < N;
-            const size_t off = (size_t)min(xb * 16 + min(row, 15), N - 1) * F + 4 * c4;
-            const f4 va = *reinterpret_cast<const f4*>(XA + off), vb = *reinterpret_cast<const f4*>(XB + off);
-            pa[i] = ok ? va : f4zero();
-            pb[i] = ok ? vb : f4zero();
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 64 * ATT_W * i, row = e / (F / 4), c4 = e % (F / 4);
-            if (e < 16 * F / 4) {
-                *reinterpret_cast<f4*>(&sm[buf][0][row * RS + 4 * c4]) = pa[i];
-                *reinterpret_cast<f4*>(&sm[buf][1][row * RS + 4 * c4]) = pb[i];
+            for (int i = 0; i < 16 / ATT_W; ++i) {
+                const int row = wv + ATT_W * i;
+                const size_t off = (size_t)min(xb * 16 + row, N - 1) * F + 4 * lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(XA + off),
+                                                 (__attribute__((address_space(3))) void*)(&sm[buf][0][row * RS]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(XB + off),
+                                                 (__attribute__((address_space(3))) void*)(&sm[buf][1][row * RS]), 16, 0, 0);
             }
         }
     };
@@ -397,7 +483,7 @@ __global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
             }
         }
     };
-    if (xb_lo < xb_hi) { fetch(xb_lo); fetch_small(xb_lo); }
+    if (xb_lo < xb_hi) { fetch(xb_lo, 0); fetch_small(xb_lo); }
 
     f4 y1[FJ], y2[MODE == MODE_FWD ? 1 : FJ];
     load_frag<F>(y1, a.Y1, y0, N, lane);
@@ -425,7 +511,7 @@ __global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
         if (yok) { qe_y = a.qe[y]; m_y = a.m[y]; inv_y = a.inv[y]; u_y = a.u[y]; D_y = a.D[y]; }
     }
     float run_m = NEG_BIG, run_l = 0.f, run_u = 0.f, run_r = 0.f;
-    if (xb_lo < xb_hi) stage(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's rows of the first tiles have landed
     __syncthreads();
 
     for (int xb = xb_lo; xb < xb_hi; ++xb) {
@@ -438,7 +524,7 @@ __global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
         if constexpr (MODE == MODE_BKV)
 #pragma unroll
             for (int r = 0; r < 20; ++r) st[r] = nst[r];
-        if (xb + 1 < xb_hi && !(AABL & 8)) { fetch(xb + 1); fetch_small(xb + 1); }
+        if (xb + 1 < xb_hi && !(AABL & 8)) { fetch(xb + 1, buf ^ 1); fetch_small(xb + 1); }
         const int x0 = xb * 16, xg = x0 + 4 * g;
         f4 t1 = (AABL & 1) ? f4{cv[0], cv[1], cv[2], cv[3]} : tile_dot<F>(tA, y1, lane);
         f4 t2 = f4zero();
@@ -501,7 +587,7 @@ __global__ __launch_bounds__(64 * ATT_W) void attn_kernel(AttnArgs a) {
                 accumulate<F>(acc2, tA, lane, dz);                                  // dK += Q^T dz
             }
         }
-        if (xb + 1 < xb_hi && !(AABL & 8)) stage(buf ^ 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // the next tiles (and this block's prefetched scalars) have landed
         __syncthreads();
     }
     const size_t slab = (size_t)blockIdx.y * N;
@@ -632,13 +718,16 @@ P conv_at(T* base, int C, int F) {
     return p;
 }
 
-// ranges of X blocks per group of 64 Y nodes: ONE workgroup per CU (the kernels hold 340-500 registers, and the ~10 us
-// a workgroup spends before its first and after its last block are paid once), never more ranges than X blocks, at most 32
-int attn_ranges(int64_t N) {
+// ranges of X blocks per group of 64 Y nodes: one workgroup per CU (the backward kernels hold 320-430 registers; the ~10 us
+// a workgroup spends before its first and after its last block are paid once; two forward workgroups per CU -- 228
+// registers allow it -- measured 55 -> 52 us but doubled the merge of the ranges: no gain); never more ranges than X
+// blocks, at most 32
+int attn_ranges(int64_t N, bool fwd = true) {
+    (void)fwd;
     const int64_t nb = (N + 15) / 16, yg = (nb + ATT_W - 1) / ATT_W;
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 32), 256 / std::min<int64_t>(yg, 256)));
 }
-int gemm_ksplits(int64_t K) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, K / 128)); }
+int gemm_ksplits(int64_t K) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, K / 256)); }
 
 // per layer: Q, K, V, R, Oa, H [N, F]; m, inv, s, qe [N]
 struct LayerWs {
@@ -691,13 +780,13 @@ int launch_attn(hipStream_t s, int F, const AttnArgs& a) {
     }
     return check("angle attention");
 }
-AttnArgs attn_base(int64_t N, int F, const float* cos, const ConvP& p, const LayerWs& L, const AngleWs& w) {
+AttnArgs attn_base(int64_t N, int F, const float* cos, const ConvP& p, const LayerWs& L, const AngleWs& w, bool fwd) {
     AttnArgs a{};
     a.cos = cos; a.we = p.we;
     a.qe = L.qe; a.m = L.m; a.inv = L.inv; a.u = w.u; a.D = w.D;
     a.part1 = w.part1; a.part2 = w.part2; a.stats = w.stats; a.qe_out = L.qe;
     a.N = (int)N;
-    const int nb = (int)((N + 15) / 16), R = attn_ranges(N);
+    const int nb = (int)((N + 15) / 16), R = attn_ranges(N, fwd);
     a.xb_per_range = (nb + R - 1) / R;
     a.scale = 1.0f / sqrtf((float)F);
     return a;
@@ -713,7 +802,7 @@ int conv_forward(hipStream_t s, int64_t N, int C, int F, const float* A, const f
     float* out[4] = {L.Q, L.K, L.V, L.R};
     for (int i = 0; i < 4; ++i) { pr[i].A[0] = X; pr[i].B[0] = Ws_[i]; pr[i].C = out[i]; pr[i].bias = bs_[i]; pr[i].npairs = 1; }
     if ((rc = launch_gemm(s, GemmShape{(int)N, F, C, C, 1, C, 1, F}, 4, pr, 0, 1, 0.0f, nullptr, nullptr))) return rc;
-    AttnArgs a = attn_base(N, F, A, p, L, w);
+    AttnArgs a = attn_base(N, F, A, p, L, w, true);
     a.Y1 = L.Q; a.X1 = L.K; a.W1 = L.V;
     if ((rc = launch_attn<MODE_FWD>(s, F, a))) return rc;
     const int ranges = (int)(((N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range);
@@ -730,7 +819,7 @@ int conv_backward(hipStream_t s, int64_t N, int C, int F, const float* A, const 
     const float beta = acc ? 1.0f : 0.0f;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)N), dim3(AT), 0, s, F, dH, L.H, L.Oa, p.we, L.s, w.u, w.D);   // dO, u, D
     if ((rc = check("angle relu_bwd"))) return rc;
-    AttnArgs a = attn_base(N, F, A, p, L, w);
+    AttnArgs a = attn_base(N, F, A, p, L, w, false);
     const int ranges = (int)(((N + 15) / 16 + a.xb_per_range - 1) / a.xb_per_range);
     // dQ = dz K + r we^T,  r = sum dz A
     a.Y1 = L.Q; a.Y2 = dH; a.X1 = L.K; a.X2 = L.V; a.W1 = L.K;

@@ -163,7 +163,7 @@ int mllp_graph_export_spmm_copy(const mllp_graph_t* g, int transpose, int which,
  *   geom 3  destination-major backward sweep (rows = the conv's destinations): 432-column blocks; replaces variant 4.
  *   geom 4  the LAYER-1 sweeps (one input channel, destination-major forward and backward; mllp_amd/csrc/lane_stream.hip,
  *           layout lane_layout.h): 512-row tiles, ONE LANE PER ROW, 20 000-column blocks of 4-byte items (a whole instance
- *           of the synthetic batch); replaces LDS-tiled variant 3.  Device builder only (where = 0).  Export: which = 0
+ *           of the synthetic batch); replaces LDS-tiled variant 3.  where = 1: host reference builder, same bytes.  Export: which = 0
  *           tile_blk, 1 tile_col (int32 x 2 per tile), 2 rows (int32 x 512 per tile), 3 column offsets (uint32 x 2 per
  *           (group, lane)), 4 tile_row, 5 headers (int32 x 2 per (tile-block, wavefront)), 6 values (float x 4 per
  *           (group, lane)); info[6] = 512 | 1 << 16 | 4 << 24.

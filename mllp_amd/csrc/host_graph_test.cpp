@@ -11,6 +11,7 @@
 #include "../../include/mllp_hip.h"
 #include "host_graph.h"
 #include "host_stream.h"
+#include "lane_layout.h"
 #include "stream_layout.h"
 
 using namespace mllp;
@@ -234,6 +235,92 @@ static void check_mps(const char* path, bool synthetic) {
 }
 
 
+static void random_csr(std::mt19937& rng, int n_dst, int n_src, double mean_deg, int long_row, std::vector<int>& ptr,
+                       std::vector<int>& idx, std::vector<float>& val) {
+    ptr.assign(1, 0);
+    for (int r = 0; r < n_dst; ++r) {
+        int deg = (int)(mean_deg * 2.0 * (rng() % 1000) / 1000.0);
+        if (rng() % 5 == 0) deg = 0;
+        if (r == 7) deg = long_row;
+        deg = std::min(deg, n_src);
+        std::vector<int> cols;
+        if (deg * 3 > n_src) {
+            std::vector<int> all(n_src);
+            for (int c = 0; c < n_src; ++c) all[c] = c;
+            for (int c = 0; c < deg; ++c) std::swap(all[c], all[c + rng() % (n_src - c)]);
+            cols.assign(all.begin(), all.begin() + deg);
+        } else {
+            while ((int)cols.size() < deg) {
+                const int c = (int)(rng() % n_src);
+                if (std::find(cols.begin(), cols.end(), c) == cols.end()) cols.push_back(c);
+            }
+        }
+        std::sort(cols.begin(), cols.end());
+        for (int c : cols) {
+            idx.push_back(c);
+            val.push_back((float)(int)(rng() % 2001 - 1000) / 1000.0f + 0.0005f);
+        }
+        ptr.push_back((int)idx.size());
+    }
+}
+
+// Lane-per-row copy of the layer-1 sweeps (host_stream.cpp::host_build_lane, layout lane_layout.h): walked the way the
+// lanes walk it, it must reproduce A x, visit every nonzero exactly once, keep the rows of a tile in descending length and
+// its tiles inside the segments; the attention geometries of the streamed layout are walked the same way as geometry 0.
+static void check_lane(std::mt19937& rng, int n_dst, int n_src, double mean_deg, int long_row, int n_seg = 1) {
+    std::vector<int> ptr, idx;
+    std::vector<float> val;
+    random_csr(rng, n_dst, n_src, mean_deg, long_row, ptr, idx, val);
+    std::vector<int64_t> seg(1, 0);
+    for (int k = 1; k < n_seg; ++k) seg.push_back((int64_t)n_dst * k / n_seg + (k & 1));
+    seg.push_back(n_dst);
+    HostLane a;
+    std::string err;
+    CHECK(host_build_lane(ptr.data(), idx.data(), val.data(), n_dst, n_seg > 1 ? seg.data() : nullptr, n_seg, &a, &err) == MLLP_OK);
+    CHECK((int)a.tile_row.size() == a.n_tiles + 1 && a.tile_row[0] == 0 && a.tile_row[a.n_tiles] == n_dst);
+    CHECK(a.real_slots == (int64_t)idx.size() && a.tile_blk[a.n_tiles] == a.n_tb);
+    CHECK(a.offs.size() == (size_t)(a.n_groups + L1_PADG) * 128 && a.vals.size() == (size_t)(a.n_groups + L1_PADG) * 256);
+    for (int t = 0; t < a.n_tiles; ++t) {
+        const int nr = a.tile_row[t + 1] - a.tile_row[t];
+        CHECK(nr > 0 && nr <= L1_R);
+        for (int64_t sgm : seg) CHECK(!(sgm > a.tile_row[t] && sgm < a.tile_row[t + 1]));
+        std::vector<int> seen(nr, 0);
+        int last = INT32_MAX;
+        for (int p = 0; p < L1_R; ++p) {
+            const int local = a.rows[(size_t)t * L1_R + p];
+            CHECK(p < nr ? (local >= 0 && local < nr) : local == -1);
+            if (local < 0) continue;
+            seen[local]++;
+            const int len = ptr[a.tile_row[t] + local + 1] - ptr[a.tile_row[t] + local];
+            CHECK(len <= last);
+            last = len;
+        }
+        for (int v : seen) CHECK(v == 1);
+        const int nb = a.tile_blk[t + 1] - a.tile_blk[t];
+        CHECK(nb == 0 ? a.tile_col[2 * t + 1] == -1 : (a.tile_col[2 * t] % 4 == 0 && (a.tile_col[2 * t + 1] - a.tile_col[2 * t]) / L1_CB + 1 == nb));
+    }
+    std::vector<float> x(n_src);
+    for (auto& v : x) v = (float)(int)(rng() % 2001 - 1000) / 500.0f;
+    std::vector<double> y(n_dst, 0.0), yref(n_dst, 0.0);
+    CHECK(host_walk_lane(a, n_dst, n_src, x.data(), y.data()) == (int64_t)idx.size());
+    for (int r = 0; r < n_dst; ++r)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) yref[r] += (double)val[e] * (double)x[idx[e]];
+    for (int r = 0; r < n_dst; ++r) CHECK(std::fabs(y[r] - yref[r]) <= 1e-9 * (1.0 + std::fabs(yref[r])));
+    // the attention geometries of the streamed layout (stream_layout.h ids 1-3) on the same matrix
+    for (int geom = 1; geom <= 3; ++geom) {
+        HostStream s;
+        CHECK(host_build_stream(ptr.data(), idx.data(), val.data(), n_dst, n_src, n_seg > 1 ? seg.data() : nullptr, n_seg, &s, &err, 4, geom) == MLLP_OK);
+        std::vector<float> H((size_t)n_src * 16);
+        for (auto& v : H) v = (float)(int)(rng() % 2001 - 1000) / 500.0f;
+        std::vector<double> Y((size_t)n_dst * 16, 0.0), Yref((size_t)n_dst * 16, 0.0);
+        CHECK(host_walk_stream(s, n_dst, n_src, H.data(), Y.data(), geom) == (int64_t)idx.size());
+        for (int r = 0; r < n_dst; ++r)
+            for (int e = ptr[r]; e < ptr[r + 1]; ++e)
+                for (int k = 0; k < 16; ++k) Yref[(size_t)r * 16 + k] += (double)val[e] * (double)H[(size_t)idx[e] * 16 + k];
+        for (size_t i = 0; i < Y.size(); ++i) CHECK(std::fabs(Y[i] - Yref[i]) <= 1e-9 * (1.0 + std::fabs(Yref[i])));
+    }
+}
+
 // Streamed SpMM copy (host_stream.cpp): random matrices that span several row tiles and column blocks (empty rows, one
 // row denser than a block's window, a ragged last tile / block); the copy is walked the way the kernel's wavefronts
 // walk it and must reproduce the CSR product, visit every nonzero exactly once, and be identical when built again
@@ -378,6 +465,11 @@ int main(int argc, char** argv) {
             check_fused(b.csc_ptr.data(), (int)b.N, b.pn, pv);
         }
     }
+    check_lane(rng, 1300, 900, 14.0, 700);         // 3 tiles (the last ragged), one block, a 700-entry row
+    check_lane(rng, 700, 45011, 30.0, 5000);       // columns over 3 blocks of 20 000
+    check_lane(rng, L1_R, 40, 3.0, 40);            // exactly one tile
+    check_lane(rng, 3000, 1500, 9.0, 30, 4);       // four segments: ragged tiles at every segment end
+    check_lane(rng, 5, 7, 0.0, 0);                 // no entries at all
     check_stream(rng, 2600, 2500, 12.0, 1400);     // 3 row tiles (the last ragged) x 4 column blocks, a 1400-entry row
     check_stream(rng, S_RR, S_CB, 3.0, S_CB);      // exactly one tile, one block, one full row
     check_stream(rng, 40, 60, 2.0, 5);

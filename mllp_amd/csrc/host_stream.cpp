@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "../../include/mllp_hip.h"
+#include "lane_layout.h"
 #include "stream_layout.h"
 
 namespace mllp {
@@ -315,6 +316,145 @@ int host_build_stream(const int* ptr, const int* idx, const float* val, int64_t 
 int64_t host_walk_stream(const HostStream& s, int64_t n_dst, int64_t n_src, const float* H, double* Y, int geom) {
     MLLP_GEOM_DISPATCH(geom, return walk_stream_t<G>(s, n_dst, n_src, H, Y))
     return -1;
+}
+
+// ------------------------------------------------------------------------------------------------ lane-per-row copy
+int host_build_lane(const int* ptr, const int* idx, const float* val, int64_t n_dst, const int64_t* seg_ptr, int64_t n_seg,
+                    HostLane* out, std::string* err) {
+    HostLane& h = *out;
+    h = HostLane();
+    std::vector<int64_t> seg;
+    if (seg_ptr && n_seg > 0) seg.assign(seg_ptr, seg_ptr + n_seg + 1);
+    else { seg.push_back(0); seg.push_back(n_dst); }
+    int64_t covered = 0;
+    for (size_t i = 0; i + 1 < seg.size(); ++i) {
+        for (int64_t r = seg[i]; r < seg[i + 1]; r += L1_R) h.tile_row.push_back((int)r);
+        covered = seg[i + 1];
+    }
+    for (int64_t r = covered; r < n_dst; r += L1_R) h.tile_row.push_back((int)r);
+    h.tile_row.push_back((int)n_dst);
+    h.n_tiles = (int)h.tile_row.size() - 1;
+    h.real_slots = n_dst > 0 ? ptr[n_dst] : 0;
+    if (n_dst <= 0) { h.n_tiles = 0; h.tile_row.assign(1, 0); }
+    h.tile_blk.assign((size_t)h.n_tiles + 1, 0);
+    h.tile_col.assign((size_t)h.n_tiles * 2, 0);
+    h.rows.assign((size_t)h.n_tiles * L1_R, -1);
+    // pass 1: the tiles' column ranges, the order of their rows, blocks per tile
+    for (int t = 0; t < h.n_tiles; ++t) {
+        const int r0 = h.tile_row[t], nr = h.tile_row[t + 1] - r0;
+        int cmin = INT32_MAX, cmax = -1;
+        std::vector<int> order(nr);
+        for (int i = 0; i < nr; ++i) {
+            order[i] = i;
+            const int b = ptr[r0 + i], e = ptr[r0 + i + 1];
+            if (e > b) { cmin = std::min(cmin, idx[b]); cmax = std::max(cmax, idx[e - 1]); }
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {      // descending length, ties by row id
+            return ptr[r0 + a + 1] - ptr[r0 + a] > ptr[r0 + b + 1] - ptr[r0 + b];
+        });
+        for (int p = 0; p < nr; ++p) h.rows[(size_t)t * L1_R + p] = order[p];
+        const int c0 = cmax < 0 ? 0 : cmin & ~3;
+        h.tile_col[2 * t] = c0;
+        h.tile_col[2 * t + 1] = cmax;
+        const int nb = cmax < 0 ? 0 : (cmax - c0) / L1_CB + 1;
+        h.tile_blk[t + 1] = h.tile_blk[t] + nb;
+        if (h.tile_blk[t + 1] >= (1 << 26)) {
+            if (err) *err = "lane copy: too many (tile, block) pairs";
+            return MLLP_ERANGE;
+        }
+    }
+    h.n_tb = h.tile_blk[h.n_tiles];
+    h.whdr.assign((size_t)h.n_tb * L1_NW * 2, 0);
+    // pass 2: groups of every (tile, wavefront, block); a row's entries of block b are those below the block's last column
+    auto row_stop = [&](int pos, int end, int nb, int b, int cb) {
+        return b + 1 == nb ? end : (int)(std::lower_bound(idx + pos, idx + end, cb + L1_CB) - idx);
+    };
+    for (int t = 0; t < h.n_tiles; ++t) {
+        const int nb = h.tile_blk[t + 1] - h.tile_blk[t], c0 = h.tile_col[2 * t];
+        for (int w = 0; w < L1_NW; ++w) {
+            std::vector<int> most(nb, 0);
+            for (int l = 0; l < 64; ++l) {
+                const int local = h.rows[(size_t)t * L1_R + 64 * w + l];
+                if (local < 0) continue;
+                int pos = ptr[h.tile_row[t] + local];
+                const int end = ptr[h.tile_row[t] + local + 1];
+                for (int b = 0; b < nb; ++b) {
+                    const int stop = row_stop(pos, end, nb, b, c0 + b * L1_CB);
+                    most[b] = std::max(most[b], stop - pos);
+                    pos = stop;
+                }
+            }
+            for (int b = 0; b < nb; ++b) h.whdr[((size_t)h.tile_blk[t] * L1_NW + (size_t)w * nb + b) * 2 + 1] = (most[b] + L1_GS - 1) / L1_GS;
+        }
+    }
+    int64_t groups = 0;
+    for (size_t i = 0; i < (size_t)h.n_tb * L1_NW; ++i) {
+        h.whdr[2 * i] = (int)groups;
+        groups += h.whdr[2 * i + 1];
+        if (groups >= (1ll << 31) / 64) {
+            if (err) *err = "lane copy: the stream exceeds int32 indexing";
+            return MLLP_ERANGE;
+        }
+    }
+    h.n_groups = groups;
+    const uint32_t padw = (uint32_t)L1_PAD | (uint32_t)L1_PAD << 16;
+    h.offs.assign((size_t)(groups + L1_PADG) * 64 * 2, padw);
+    h.vals.assign((size_t)(groups + L1_PADG) * 64 * 4, 0.0f);
+    // pass 3: the entries
+    for (int t = 0; t < h.n_tiles; ++t) {
+        const int nb = h.tile_blk[t + 1] - h.tile_blk[t], c0 = h.tile_col[2 * t];
+        for (int p = 0; p < L1_R; ++p) {
+            const int local = h.rows[(size_t)t * L1_R + p];
+            if (local < 0) continue;
+            const int w = p >> 6, l = p & 63;
+            int pos = ptr[h.tile_row[t] + local];
+            const int end = ptr[h.tile_row[t] + local + 1];
+            for (int b = 0; b < nb; ++b) {
+                const int cb = c0 + b * L1_CB, stop = row_stop(pos, end, nb, b, cb);
+                const int* hd = &h.whdr[((size_t)h.tile_blk[t] * L1_NW + (size_t)w * nb + b) * 2];
+                for (int e = pos; e < stop; ++e) {
+                    const int s = e - pos;
+                    const size_t slot = ((size_t)hd[0] + s / 4) * 64 + l;
+                    uint32_t& word = h.offs[slot * 2 + ((s & 3) >> 1)];
+                    const uint32_t o = (uint32_t)(idx[e] - cb);
+                    word = (s & 1) ? ((word & 0xffffu) | o << 16) : ((word & 0xffff0000u) | o);
+                    h.vals[slot * 4 + (s & 3)] = val[e];
+                }
+                pos = stop;
+            }
+        }
+    }
+    return MLLP_OK;
+}
+
+int64_t host_walk_lane(const HostLane& s, int64_t n_dst, int64_t n_src, const float* x, double* y) {
+    int64_t real = 0;
+    if ((int)s.tile_row.size() != s.n_tiles + 1 || (int)s.tile_blk.size() != s.n_tiles + 1) return -1;
+    for (int t = 0; t < s.n_tiles; ++t) {
+        const int nb = s.tile_blk[t + 1] - s.tile_blk[t], c0 = s.tile_col[2 * t];
+        for (int w = 0; w < L1_NW; ++w)
+            for (int b = 0; b < nb; ++b) {
+                const int* hd = &s.whdr[((size_t)s.tile_blk[t] * L1_NW + (size_t)w * nb + b) * 2];
+                for (int g = 0; g < hd[1]; ++g)
+                    for (int l = 0; l < 64; ++l) {
+                        const size_t slot = ((size_t)hd[0] + g) * 64 + l;
+                        if ((slot + 1) * 4 > s.vals.size()) return -1;
+                        const int local = s.rows[(size_t)t * L1_R + 64 * w + l];
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t o = (s.offs[slot * 2 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
+                            if (o == (uint32_t)L1_PAD) {
+                                if (s.vals[slot * 4 + k] != 0.0f) return -1;
+                                continue;
+                            }
+                            const int64_t col = (int64_t)c0 + (int64_t)b * L1_CB + o, row = (int64_t)s.tile_row[t] + local;
+                            if (local < 0 || o >= (uint32_t)L1_CB || col >= n_src || row >= s.tile_row[t + 1] || row >= n_dst) return -1;
+                            y[row] += (double)s.vals[slot * 4 + k] * (double)x[col];
+                            ++real;
+                        }
+                    }
+            }
+    }
+    return real;
 }
 
 }  // namespace mllp

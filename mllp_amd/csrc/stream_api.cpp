@@ -49,6 +49,34 @@ static int build_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t
     return MLLP_OK;
 }
 
+static int build_lane_on_host(const Orient& o, int64_t nnz, const std::vector<int64_t>& seg, LaneCopy& lc, hipStream_t s) {
+    std::vector<int> ptr((size_t)o.n_dst + 1, 0), idx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
+    MLLP_HIP_TRY(hipStreamSynchronize(s));
+    MLLP_HIP_TRY(hipMemcpy(ptr.data(), o.ptr, ((size_t)o.n_dst + 1) * 4, hipMemcpyDeviceToHost));
+    if (nnz > 0) {
+        MLLP_HIP_TRY(hipMemcpy(idx.data(), o.idx, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+        MLLP_HIP_TRY(hipMemcpy(val.data(), o.val, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+    }
+    HostLane h;
+    std::string err;
+    const int rc = host_build_lane(ptr.data(), idx.data(), val.data(), o.n_dst, seg.data(), (int64_t)seg.size() - 1, &h, &err);
+    if (rc) return fail(rc, err);
+    auto up = [&](void** d, const void* src, size_t bytes) -> int {
+        MLLP_HIP_TRY(hipMalloc(d, std::max<size_t>(bytes, 4)));
+        if (bytes) MLLP_HIP_TRY(hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice));
+        return MLLP_OK;
+    };
+    int r;
+    if ((r = up((void**)&lc.tile_row, h.tile_row.data(), h.tile_row.size() * 4)) || (r = up((void**)&lc.tile_blk, h.tile_blk.data(), h.tile_blk.size() * 4)) ||
+        (r = up((void**)&lc.tile_col, h.tile_col.data(), h.tile_col.size() * 4)) || (r = up((void**)&lc.rows, h.rows.data(), h.rows.size() * 4)) ||
+        (r = up((void**)&lc.whdr, h.whdr.data(), h.whdr.size() * 4)) || (r = up((void**)&lc.offs, h.offs.data(), h.offs.size() * 4)) ||
+        (r = up((void**)&lc.vals, h.vals.data(), h.vals.size() * 4)))
+        return r;
+    lc.n_tiles = h.n_tiles; lc.n_tb = h.n_tb; lc.n_groups = h.n_groups; lc.nnz = nnz;
+    return MLLP_OK;
+}
+
 }  // namespace mllp
 
 using namespace mllp;
@@ -77,14 +105,14 @@ StreamCopy* copy_slot(mllp_graph_t* g, int transpose, int geom) {
 extern "C" int mllp_graph_build_stream_copy(mllp_graph_t* g, int transpose, int geom, int where, void* stream) {
     REQUIRE(g, "null graph");
     REQUIRE(where == 0 || where == 1, "where must be 0 (device builder) or 1 (host reference builder)");
-    if (geom == STREAM_GEOM_LANE1) {         // the lane-per-row copy of the layer-1 sweeps (lane_layout.h): device builder only
-        REQUIRE(where == 0, "geometry 4 has no host builder");
+    if (geom == STREAM_GEOM_LANE1) {         // the lane-per-row copy of the layer-1 sweeps (lane_layout.h)
         Orient& o = transpose ? g->At : g->A;
         lane_copy_free(o.lane1);
         if (o.n_dst == 0) return MLLP_OK;
         const auto t0 = std::chrono::steady_clock::now();
         LaneCopy lc;
-        const int rc = build_lane_copy(o, g->nnz, transpose ? g->h_inst_ptr_n : g->h_inst_ptr_m, lc, (hipStream_t)stream);
+        const std::vector<int64_t>& lseg = transpose ? g->h_inst_ptr_n : g->h_inst_ptr_m;
+        const int rc = where == 1 ? build_lane_on_host(o, g->nnz, lseg, lc, (hipStream_t)stream) : build_lane_copy(o, g->nnz, lseg, lc, (hipStream_t)stream);
         if (rc) {
             lane_copy_free(lc);
             return rc;

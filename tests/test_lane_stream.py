@@ -2,9 +2,9 @@
 (mllp_amd/csrc/lane_stream.hip; layout lane_layout.h, geometry 4 of mllp_graph_build_stream_copy), through the C ABI,
 against the fp64 oracle of the reference's TransformerConv(1, 16, edge_dim=1) (oracle/spmm_form.py::conv_fwd / conv_bwd)
 -- reference linear_program_methods.py:90-91, 241-242 -- and against the generic sweeps of the same library.
-Covered: the copy (decoded the way the lanes walk it: a permutation of the CSR; rows of a tile ordered by length; padding
-entries), ragged batches (empty rows, rows of 1-3 and of hundreds of entries, tiny instances, an instance without
-nonzeros, tiles of exactly 512 / 513 rows), instances wider than one column block (3 blocks per tile), the 97 Netlib
+Covered: the copy (device builder == host reference builder, bit for bit; decoded the way the lanes walk it: a permutation
+of the CSR; rows of a tile ordered by length; padding entries), ragged batches (empty rows, rows of 1-3 and of hundreds of
+entries, tiny instances, an instance without nonzeros, tiles of exactly 512 / 513 rows), instances wider than one column block (3 blocks per tile), the 97 Netlib
 instances, run-to-run determinism."""
 import numpy as np
 import pytest
@@ -100,6 +100,10 @@ def test_lane_copy_permutes_the_csr(LPBatch):
         info = b.build_stream_copy(transpose, GEOM)
         assert info["row_slots"] == 512 and info["cols_per_block"] == 20000 and info["wavefronts"] == 8 and info["item_bytes"] == 4
         copy = b.export_stream_copy(transpose, GEOM)
+        b.build_stream_copy(transpose, GEOM, "host")                     # the host reference builder: the same bytes
+        host = b.export_stream_copy(transpose, GEOM)
+        for name, h_, d_ in zip(("tile_blk", "tile_col", "rows", "offs", "tile_row", "whdr", "vals"), host, copy):
+            assert h_.shape == d_.shape and np.array_equal(h_, d_), f"device builder differs from the host reference builder in {name}"
         n_dst = b.N if transpose else b.M
         tile_row = copy[4]
         bounds = np.concatenate([[0], np.cumsum(b.inst_n if transpose else b.inst_m)])

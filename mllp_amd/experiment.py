@@ -171,7 +171,7 @@ def load_checkpoint(path, trainer, train_dict, device):
 def train_angle(cfg, method_name, train_dataset, train_dict, out=print):
     """reference linear_program_experiment.py:81-114: AngleModel(feat_dim=256) on the complete angle graph of the
     dense dataset's instance, BCEWithLogits + Adam, top-k metrics, train_log.json, state_dict .pt."""
-    from .angle import AngleModel, get_netlib_dataloader
+    from .angle import AngleModel, AngleStepper, get_netlib_dataloader
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # one instance, one dense graph: nothing to shard, and N ranks would all write the same files
@@ -183,19 +183,17 @@ def train_angle(cfg, method_name, train_dataset, train_dict, out=print):
                            "there is no CPU fallback")
     train_loader = get_netlib_dataloader(train_dataset, device)                     # reference :33
     model = AngleModel(feat_dim=int(cfg.get_default("angle_feat_dim"))).to(device)  # reference :83
-    criterion = torch.nn.BCEWithLogitsLoss()                                        # reference :41
-    train_optimizer = torch.optim.Adam(model.parameters(), lr=cfg.train_lr)         # reference :87
+    # reference :41, :87-96: BCEWithLogitsLoss + torch.optim.Adam around autograd -- here the same arithmetic on flat
+    # parameters without autograd (AngleStepper: C ABI forward / backward, the library's Adam kernel; tests/test_angle.py
+    # checks it step for step against the nn.Module + torch.optim loop), 2-3 x faster per step on small instances
+    stepper = AngleStepper(model, lr=cfg.train_lr)
     for epoch in range(cfg.train_iter):
         obj_sum = 0.0
         for graph in train_loader:
             name, basis_num, var_num = graph.name, graph.basis_num, graph.var_num
             basis_opt = torch.tensor(np.asarray(graph.basis_opt), dtype=torch.float, device=device)
-            train_optimizer.zero_grad()
-            latent_vars = model(graph)
-            obj = criterion(latent_vars, basis_opt)
-            obj.backward()
+            obj, latent_vars = stepper.step(graph, basis_opt)
             obj_sum += float(obj.detach())
-            train_optimizer.step()
             pred_indices = torch.topk(latent_vars, k=basis_num)[-1].cpu().detach().numpy()
             pred = np.zeros(var_num)
             pred[pred_indices] = 1
@@ -210,6 +208,7 @@ def train_angle(cfg, method_name, train_dataset, train_dict, out=print):
             json.dump(train_dict, json_file)
         out(f"epoch {epoch}, obj={obj_sum / len(train_dataset)}")
     model_path = f"linear_program_{cfg.train_data_type}_{method_name}.pt"
+    model.load_flat(stepper.params)
     torch.save(model.state_dict(), model_path)                                      # reference :176
     out(f"Model saved to {model_path}.")
     return train_dict

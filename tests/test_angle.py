@@ -144,7 +144,7 @@ def test_angle_stepper_equals_module_loop():
         loss.backward()
         opt.step()
         loss2, _ = st.step(g, y)
-        assert abs(float(loss) - float(loss2)) <= 2e-6 * abs(float(loss))
+        assert abs(float(loss.detach()) - float(loss2)) <= 2e-6 * abs(float(loss.detach()))
     a, b = model.flat_parameters().detach(), st.params
     keep = (a - b).abs() <= 2e-5 * a.abs().max()
     assert bool(keep.all())

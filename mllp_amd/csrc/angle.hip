@@ -377,13 +377,21 @@ __device__ __forceinline__ f4 tile_dot(const float* __restrict__ tile, const f4 
     // four independent chains: with two, a dependent MFMA issued every ~53 cycles instead of 32 (measured: the dot
     // products ran at 0.6 of the rate of the 16-chain accumulation)
     f4 t0 = f4zero(), t1 = f4zero(), t2 = f4zero(), t3 = f4zero();
+    // The four chains must stay INTERLEAVED: left alone, the scheduler ran two chains at a time (to shorten the live range of
+    // the operand rows), and a dependent MFMA every second slot issues every ~57 cycles instead of 32 (cycle stamps:
+    // profiles/r04_angle_cycles.txt).  Hence: all reads of the tile row first (they return in order), then the MFMAs with a
+    // scheduling barrier behind every group of four.
+    f4 xa[F / 16];
+#pragma unroll
+    for (int j = 0; j < F / 16; ++j) xa[j] = *reinterpret_cast<const f4*>(p + 16 * j);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < F / 16; ++j) {
-        const f4 xa = *reinterpret_cast<const f4*>(p + 16 * j);
-        t0 = mfma4(xa[0], yb[j][0], t0);
-        t1 = mfma4(xa[1], yb[j][1], t1);
-        t2 = mfma4(xa[2], yb[j][2], t2);
-        t3 = mfma4(xa[3], yb[j][3], t3);
+        t0 = mfma4(xa[j][0], yb[j][0], t0);
+        t1 = mfma4(xa[j][1], yb[j][1], t1);
+        t2 = mfma4(xa[j][2], yb[j][2], t2);
+        t3 = mfma4(xa[j][3], yb[j][3], t3);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return (t0 + t1) + (t2 + t3);
 }
@@ -436,6 +444,17 @@ constexpr int ATT_W = 4;                  // wavefronts (= Y blocks of 16 nodes)
 #define MLLP_ANGLE_ABL 0                  // 4 no softmax arithmetic, 8 no staging of the next tiles
 #endif
 constexpr int AABL = MLLP_ANGLE_ABL;
+#ifdef MLLP_TIMING_BUILD
+// cycle stamps of the attention kernels (timing library only; tools/angle_cycles.py): per MODE {wavefronts, prologue, dot
+// products, arithmetic, accumulation, wait for the next tiles, barrier, epilogue, issue of the next block's loads, first
+// tile read} summed over the wavefronts (s_memtime)
+}  // namespace
+__device__ unsigned long long g_angle_stamps[3][10];
+namespace {
+#define ANGLE_TICK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; }
+#else
+#define ANGLE_TICK(k)
+#endif
 
 // One workgroup = 4 wavefronts = 64 Y nodes, one range of X blocks.  The two matrices of an X block (FWD: K, V; BQ: K, V;
 // BKV: Q, dO -- each serves as the operand of a dot product AND of an accumulation) are staged by LDS-DMA one block ahead
@@ -445,6 +464,9 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
     constexpr int FJ = F / 16, NA = (F + 63) / 64 * 4, RS = F + 4, TILE = 16 * RS;
     __shared__ __attribute__((aligned(16))) float sm[2][2][TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4;
+#ifdef MLLP_TIMING_BUILD
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
     const int N = a.N;
     const int y0 = (blockIdx.x * ATT_W + wv) * 16, y = y0 + (lane & 15);
     const int n_xb = (N + 15) / 16;
@@ -471,14 +493,15 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
         }
     };
     // the edge attributes of the block (and, BKV, the scalars of its X nodes) also come one block ahead
+    // (no guards, hence no branches: clamped addresses; whatever belongs to a node >= N is masked where it is used)
     float ncv[4], nst[MODE == MODE_BKV ? 20 : 1];
     auto fetch_small = [&](int xb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int x = xb * 16 + 4 * g + r;
-            ncv[r] = (yok && x < N) ? cosrow[x] : 0.0f;      // (the matrix is symmetric: A[y][x] serves both orientations)
-            if constexpr (MODE == MODE_BKV) {
-                const int xc = min(x, N - 1);
+        for (int r = 0; r < 4; ++r) ncv[r] = cosrow[min(xb * 16 + 4 * g + r, N - 1)];     // (symmetric: A[y][x] serves both orientations)
+        if constexpr (MODE == MODE_BKV) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xc = min(xb * 16 + 4 * g + r, N - 1);
                 nst[r] = a.qe[xc]; nst[4 + r] = a.m[xc]; nst[8 + r] = a.inv[xc]; nst[12 + r] = a.u[xc]; nst[16 + r] = a.D[xc];
             }
         }
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
     float run_m = NEG_BIG, run_l = 0.f, run_u = 0.f, run_r = 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's rows of the first tiles have landed
     __syncthreads();
+    ANGLE_TICK(1)
 
     for (int xb = xb_lo; xb < xb_hi; ++xb) {
         const int buf = (xb - xb_lo) & 1;
@@ -525,10 +549,23 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
 #pragma unroll
             for (int r = 0; r < 20; ++r) st[r] = nst[r];
         if (xb + 1 < xb_hi && !(AABL & 8)) { fetch(xb + 1, buf ^ 1); fetch_small(xb + 1); }
+        ANGLE_TICK(8)
+#ifdef MLLP_TIMING_BUILD
+        {   // how long the first read of the current tile takes behind the DMA issue (the compiler orders LDS reads behind
+            // global_load_lds with vmcnt(0))
+            float probe = tA[lane];
+            asm volatile("s_nop 0" : "+v"(probe));
+            ANGLE_TICK(9)
+        }
+#endif
         const int x0 = xb * 16, xg = x0 + 4 * g;
         f4 t1 = (AABL & 1) ? f4{cv[0], cv[1], cv[2], cv[3]} : tile_dot<F>(tA, y1, lane);
         f4 t2 = f4zero();
         if constexpr (MODE != MODE_FWD) t2 = (AABL & 1) ? t1 : tile_dot<F>(tB, y2, lane);
+#ifdef MLLP_TIMING_BUILD
+        asm volatile("s_nop 0" : "+v"(t1), "+v"(t2));      // (the stamp behind the MFMAs' results)
+#endif
+        ANGLE_TICK(2)
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -558,6 +595,10 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
             }
             run_l = fmaf(run_l, al, ps);
             run_u = fmaf(run_u, al, pu);
+#ifdef MLLP_TIMING_BUILD
+            asm volatile("s_nop 0" : "+v"(p), "+v"(run_l));
+#endif
+            ANGLE_TICK(3)
             if (__builtin_expect(__any(al != 1.0f), 0)) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) acc1[i] *= al;
@@ -577,9 +618,13 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
                 const float L = fmaf(qe_[r], cv[r], t1[r]) * a.scale;
                 p[r] = (AABL & 4) ? L : (ok[r] ? exp_acc(L - m_[r]) * inv_[r] : 0.0f);
                 const float dp = fmaf(u_[r], cv[r], t2[r]);
-                dz[r] = p[r] * (dp - D_[r]) * a.scale;
+                dz[r] = ok[r] ? p[r] * (dp - D_[r]) * a.scale : 0.0f;      // (the scalars of a node >= N are whatever the padding holds)
                 run_r = fmaf(dz[r], cv[r], run_r);
             }
+#ifdef MLLP_TIMING_BUILD
+            asm volatile("s_nop 0" : "+v"(p), "+v"(dz));
+#endif
+            ANGLE_TICK(3)
             if (AABL & 2) { acc1[0] += dz; acc1[1] += p; }
             else if constexpr (MODE == MODE_BQ) accumulate<F>(acc1, tA, lane, dz);      // dQ += K^T dz
             else {
@@ -587,12 +632,35 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
                 accumulate<F>(acc2, tA, lane, dz);                                  // dK += Q^T dz
             }
         }
+#ifdef MLLP_TIMING_BUILD
+        asm volatile("s_nop 0" : "+v"(acc1[0]), "+v"(acc1[NA - 1]));
+#endif
+        ANGLE_TICK(4)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // the next tiles (and this block's prefetched scalars) have landed
+        ANGLE_TICK(5)
         __syncthreads();
+        ANGLE_TICK(6)
     }
+    // The partial accumulators leave through LDS (the tiles are free now; every wavefront has a 16 x F region of its own): in
+    // registers a store instruction covers 16 rows x 64 bytes, out of LDS one whole row -- the 64-byte pieces made the
+    // epilogue 13-24 % of the kernel (cycle stamps, profiles/r04_angle_cycles.txt).
     const size_t slab = (size_t)blockIdx.y * N;
-    store_acc<F>(acc1, a.part1 + slab * F, y, N, lane);
-    if constexpr (MODE == MODE_BKV) store_acc<F>(acc2, a.part2 + slab * F, y, N, lane);
+    float* region = &sm[0][0][0] + wv * TILE;
+    auto store_rows = [&](const f4 (&acc)[NA], float* __restrict__ out) {
+#pragma unroll
+        for (int u = 0; u < (F + 63) / 64; ++u)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int f0 = 64 * u + 16 * g + 4 * rr;
+                if (f0 < F) *reinterpret_cast<f4*>(region + (lane & 15) * RS + f0) = f4{acc[4 * u][rr], acc[4 * u + 1][rr], acc[4 * u + 2][rr], acc[4 * u + 3][rr]};
+            }
+        const int c4 = min(4 * lane, F - 4);          // (F < 256: the lanes behind the row repeat its last 16 bytes)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (y0 + i < N) *reinterpret_cast<f4*>(out + (size_t)(y0 + i) * F + c4) = *reinterpret_cast<const f4*>(region + i * RS + c4);
+    };
+    store_rows(acc1, a.part1 + slab * F);
+    if constexpr (MODE == MODE_BKV) store_rows(acc2, a.part2 + slab * F);
     if constexpr (MODE == MODE_FWD) {
         run_l = group_sum(run_l);
         run_u = group_sum(run_u);
@@ -601,6 +669,14 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
         run_r = group_sum(run_r);
         if (g == 0 && yok) a.stats[(slab + y) * 4] = run_r;
     }
+#ifdef MLLP_TIMING_BUILD
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ANGLE_TICK(7)
+    if (lane == 0) {
+        atomicAdd(&g_angle_stamps[MODE][0], 1ull);
+        for (int k = 1; k < 10; ++k) atomicAdd(&g_angle_stamps[MODE][k], tacc[k]);
+    }
+#endif
 }
 
 // merge of the forward ranges and the layer's epilogue: Oa = alpha V, s = sum alpha A, H = relu(Oa + s we + R).
@@ -867,6 +943,20 @@ int conv_backward(hipStream_t s, int64_t N, int C, int F, const float* A, const 
 }
 
 bool feat_ok(int F) { return F == 16 || F == 32 || F == 64 || F == 128 || F == 256; }
+
+}  // namespace
+}  // namespace mllp
+#ifdef MLLP_TIMING_BUILD
+// timing library only: read (and clear) the attention kernels' cycle stamps, [3 modes][10]
+extern "C" int mllp_debug_angle_stamps(unsigned long long* host) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mllp::g_angle_stamps), sizeof(unsigned long long) * 30) != hipSuccess) return -1;
+    static const unsigned long long zero[30] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mllp::g_angle_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+namespace mllp {
+namespace {
 
 }  // namespace
 }  // namespace mllp

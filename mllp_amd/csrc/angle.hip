@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * ATT_W, MODE == MODE_FWD ? 2 : 1) void attn_ker
 #pragma unroll
             for (int i = 0; i < 16 / ATT_W; ++i) {
                 const int row = wv + ATT_W * i;
-                const size_t off = (size_t)min(xb * 16 + row, N - 1) * F + 4 * lane;
+                const int off = min(xb * 16 + row, N - 1) * F + 4 * lane;        // (N F < 2^31: 32-bit address arithmetic)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(XA + off),
                                                  (__attribute__((address_space(3))) void*)(&sm[buf][0][row * RS]), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(XB + off),

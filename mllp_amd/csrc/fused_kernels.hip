@@ -1668,8 +1668,12 @@ struct TailArgs {
 // holds the device.  The spin is bounded so that a workgroup that is never scheduled cannot hang the others; a timeout is
 // NOT silent: the workgroup raises the error word and the kernel skips Adam and the weight folding -- also in
 // the workgroups that arrive late and find the count complete -- and the host refuses the next call.
-__device__ __forceinline__ bool tail_barrier(unsigned long long* cnt, unsigned long long target, unsigned* err) {
+// The error word the workgroups LOOK at lives in device memory (word 2 of the barrier state): the first version read the
+// host-mapped word after every barrier -- one PCIe round trip per workgroup on the step's critical path, 20.7 -> 27.3 us for
+// the kernel.  The host-mapped word is only written, on a timeout, for the host's check before the next launch.
+__device__ __forceinline__ bool tail_barrier(unsigned long long* cnt, unsigned long long target, unsigned* err_host) {
     __shared__ int ok_s;
+    unsigned long long* err_dev = cnt + 2;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -1677,9 +1681,12 @@ __device__ __forceinline__ bool tail_barrier(unsigned long long* cnt, unsigned l
         int spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(8);
-        if (spins >= (1 << 22)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (spins >= (1 << 22)) {
+            __hip_atomic_store(err_dev, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __threadfence();
-        ok_s = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
+        ok_s = __hip_atomic_load(err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
     }
     __syncthreads();
     return ok_s != 0;
@@ -1770,8 +1777,13 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((int64_t)g->h_csr_ptr.size() != g->M + 1 && !h_csr_ptr) return fail(MLLP_EINVAL, "fused path: no host row pointers");
     HostFusedOrient hc, hv;
     {
+#ifdef MLLP_SCALAR_PARTITION       // (experiment: the one-cost rule of rounds 2-3)
+        const std::vector<int> part = host_partition_instances(host_instance_cost(h_csr_ptr, g->h_inst_ptr_m),
+                                                               host_instance_cost(h_csc_ptr, g->h_inst_ptr_n), FUSED_PARTS);
+#else
         const std::vector<int> part = host_partition_instances_v(host_instance_loads(h_csr_ptr, g->h_inst_ptr_m),
                                                                  host_instance_loads(h_csc_ptr, g->h_inst_ptr_n), FUSED_PARTS);
+#endif
         host_build_fused_orient(h_csr_ptr, (int)g->M, g->h_inst_ptr_m, part, &hc);     // constraints by (partition, row length)
         host_build_fused_orient(h_csc_ptr, (int)g->N, g->h_inst_ptr_n, part, &hv);     // variables by (partition, column length)
     }
@@ -1818,8 +1830,8 @@ int fused_graph_build(mllp_graph* g, const int* h_csr_ptr, const int* h_csc_ptr)
     if ((rc = dev_alloc(g, (size_t)g->M, &g->x2_p))) return rc;
     if ((rc = dev_alloc(g, (size_t)g->N, &g->labels_p))) return rc;
     if (!g->tail_sync) {
-        if ((rc = dev_alloc(g, (size_t)2, &g->tail_sync))) return rc;
-        MLLP_HIP_TRY(hipMemset(g->tail_sync, 0, 16));
+        if ((rc = dev_alloc(g, (size_t)4, &g->tail_sync))) return rc;
+        MLLP_HIP_TRY(hipMemset(g->tail_sync, 0, 32));
         MLLP_HIP_TRY(hipHostMalloc((void**)&g->tail_err_host, 64, hipHostMallocMapped));
         *g->tail_err_host = 0u;
         MLLP_HIP_TRY(hipHostGetDevicePointer((void**)&g->tail_err_dev, g->tail_err_host, 0));

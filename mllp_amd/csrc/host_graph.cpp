@@ -173,6 +173,13 @@ std::vector<InstLoad> host_instance_loads(const int* ptr, const std::vector<int6
             else if (deg > FUSED_T1[1]) { l.d[2] += 64; l.d[3] += 64 * ((deg + 511) / 512); }
             else if (deg > FUSED_T1[0]) { l.d[2] += 4; l.d[3] += 4 * ((deg + 31) / 32); }
             else { l.d[2] += 1; l.d[3] += std::max<int64_t>((deg + 7) / 8, 1); }
+            // the one-cost model of rounds 2-3 (host_instance_cost) as a quantity of its own: balanced by items and steps
+            // alone, fused_fwd16 / fused_bwd16 ran 2 us slower per launch than under that model, the other three families
+            // 1-2 us faster (same-box A/B, profiles/r04_fused_stamps.txt); with both, every family keeps its better figure
+            if (deg > FUSED_T16[2]) l.d[5] += 12 * FUSED_COST_BLOCK_ROW;
+            else if (deg > FUSED_T16[1]) l.d[5] += FUSED_COST_ITEM + FUSED_COST_STEP * ((deg + 63) / 64);
+            else if (deg > FUSED_T16[0]) l.d[5] += (FUSED_COST_ITEM + FUSED_COST_STEP * ((deg + 15) / 16)) / 4;
+            else l.d[5] += (FUSED_COST_ITEM + FUSED_COST_STEP * ((deg + 3) / 4)) / 16;
         }
     }
     return out;
@@ -201,7 +208,8 @@ double host_partition_imbalance(const std::vector<InstLoad>& a, const std::vecto
                                 int n_parts) {
     double worst = 0.0;
     for (int side = 0; side < 2; ++side)
-        for (int d = 0; d < FUSED_LOAD_DIMS - 1; ++d) {
+        for (int d = 0; d < FUSED_LOAD_DIMS; ++d) {
+            if (d == 4) continue;                    // (block rows: counted as items)
             std::vector<double> l((size_t)n_parts, 0.0);
             double tot = 0.0;
             for (size_t i = 0; i < a.size(); ++i) {
@@ -292,7 +300,11 @@ std::vector<int> host_partition_instances_v(const std::vector<InstLoad>& a, cons
             if (bj >= 0) part[(size_t)bj] = wq;
         }
     }
-    return part;
+    // the one-cost rule's deal is a candidate too: whichever has the lower largest load over all quantities
+    std::vector<int64_t> ca((size_t)n), cb((size_t)n);
+    for (int i = 0; i < n; ++i) { ca[(size_t)i] = a[(size_t)i].d[5]; cb[(size_t)i] = b[(size_t)i].d[5]; }
+    const std::vector<int> alt = host_partition_instances(ca, cb, n_parts);
+    return host_partition_imbalance(a, b, alt, n_parts) < host_partition_imbalance(a, b, part, n_parts) - 1e-12 ? alt : part;
 }
 
 std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, const std::vector<int64_t>& cost_b, int n_parts) {

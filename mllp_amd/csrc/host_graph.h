@@ -95,9 +95,10 @@ std::vector<int> host_partition_instances(const std::vector<int64_t>& cost_a, co
 // (a block row in items: the model of rounds 2-3 charged 25 k cycles to each of the 12 wavefronts = 43 items, and the partition
 // that held the Netlib batch's block rows ran 25 % under the mean; the stamps of round 4 fit 10)
 constexpr int FUSED_BLOCK_ROW_ITEMS = 10;
-constexpr int FUSED_LOAD_DIMS = 5;       // {items16, steps16, items1, steps1, block rows} of one orientation, fixed point
+constexpr int FUSED_LOAD_DIMS = 6;       // {items16, steps16, items1, steps1, block rows, modelled cycles of a 16-channel sweep}
+                                         // of one orientation, fixed point
 struct InstLoad {
-    int64_t d[FUSED_LOAD_DIMS] = {0, 0, 0, 0, 0};
+    int64_t d[FUSED_LOAD_DIMS] = {0, 0, 0, 0, 0, 0};
 };
 std::vector<InstLoad> host_instance_loads(const int* ptr, const std::vector<int64_t>& inst_off);
 // Deterministic.  Largest instance first, each to the partition that keeps the largest normalised load over all 2 x 5

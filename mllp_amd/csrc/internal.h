@@ -138,7 +138,7 @@ struct mllp_graph {
     int* inv_v = nullptr;        // [N] original -> renumbered
     int* inv_c = nullptr;        // [M]
     float* inv_n_p = nullptr;    // [N] 1 / n_k in renumbered order
-    unsigned long long* tail_sync = nullptr;   // [2] grid-barrier state of fused_tail_kernel {arrivals, launches}
+    unsigned long long* tail_sync = nullptr;   // [4] grid-barrier state of fused_tail_kernel {arrivals, launches, error word, -}
     unsigned* tail_err_host = nullptr;         // host-mapped word that the kernel raises when its barrier times out
     unsigned* tail_err_dev = nullptr;          // ... its device address
     float* x1_p = nullptr;       // [N] bound inputs in renumbered order

@@ -8,6 +8,9 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("MLLP_LIB"):              # experiments: a variant build of the library (tools/variant_lib.sh)
+    from mllp_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "mllp_amd", "csrc", os.environ["MLLP_LIB"])
 from mllp_amd.data import load_packed  # noqa: E402
 from mllp_amd.graph import LPBatch, synthetic_batch  # noqa: E402
 from mllp_amd.trainer import LPTrainer  # noqa: E402

@@ -191,3 +191,26 @@ def test_lane_layer1_full_netlib(LPBatch, sd9):
     insts = load_packed()
     _layer1_case(LPBatch, insts, sd9, "gconv1_w2s", True, 0, seed=7, what="netlib w2s")
     _layer1_case(LPBatch, insts, sd9, "gconv1_s2w", False, 144, seed=8, what="netlib s2w")
+
+
+def test_skewed_batch_does_not_keep_a_padded_copy(LPBatch):
+    """A batch in which every tile has ONE row far longer than the other 63 of its wavefront would cost the lane-per-row copy
+    64 slots per entry of that row: `enable_stream_step` drops a copy that needs more than two slots per nonzero, and the
+    layer-1 conv then runs on the generic sweeps (same results)."""
+    rng = np.random.default_rng(3)
+    m, n = 600, 30000
+    rows = [np.sort(rng.choice(n, size=2, replace=False)).astype(np.int32) for _ in range(m)]
+    for r in range(0, m, 64):
+        rows[r] = np.sort(rng.choice(n, size=4000, replace=False)).astype(np.int32)
+    indptr = np.zeros(m + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    inst = LPInstance("skewed", indptr, np.concatenate(rows).astype(np.int32), rng.standard_normal(indptr[-1]),
+                      rng.standard_normal(n), rng.random(m) * 5, (rng.random(n) < 0.37).astype(np.int32))
+    b = LPBatch.from_instances([inst])
+    raw = b.build_stream_copy(False, GEOM)
+    assert raw["entry_slots"] > 2 * b.nnz
+    infos = b.enable_stream_step()
+    assert infos[(False, GEOM)].get("dropped") and b.stream_copy_info(False, GEOM)["n_tiles"] == 0
+    for (tr, g), i in infos.items():            # the rule, for every copy of the step
+        kept = b.stream_copy_info(tr, g)["n_tiles"] > 0
+        assert kept == (i["entry_slots"] <= 2 * b.nnz) and kept == (not i.get("dropped")), (tr, g, i)

@@ -411,25 +411,39 @@ __global__ __launch_bounds__(BLOCK) void head_kernel(int mode, int n, const floa
     const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
     const float w = fcw[c], b = fcb[0];
     float accw = 0.0f, accb = 0.0f, accl = 0.0f;
-    for (int i = blockIdx.x * 16 + grp; i < n; i += gridDim.x * 16) {
-        const float hv = h[(size_t)i * 16 + c];
-        const float z = row16_sum(hv * w) + b;
-        if (c == 0 && logits) logits[i] = z;
-        if (mode == 0) continue;
-        float dz;
-        if (mode == 1) {
-            dz = dz_in[i];
-        } else {
-            const float y = labels[i];
-            const float wn = inv_n[i] * inv_batch;
-            const float e = expf(-fabsf(z));
-            const float sig = z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-            dz = wn * (sig - y);
-            accl += wn * (fmaxf(z, 0.0f) - z * y + log1pf(e));
+    // four nodes per 16-lane group in flight: with one, the 312 dependent load -> store rounds of a group at 5.12 M nodes made
+    // the kernel 0.53 ms for 0.7 GB (latency, not bandwidth)
+    constexpr int HU = 4;
+    const int stride = gridDim.x * 16;
+    for (int i0 = blockIdx.x * 16 + grp; i0 < n; i0 += HU * stride) {
+        float hv[HU], yv[HU], wv[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int i = min(i0 + u * stride, n - 1);
+            hv[u] = h[(size_t)i * 16 + c];
+            yv[u] = mode == 1 ? dz_in[i] : mode == 2 ? labels[i] : 0.0f;
+            wv[u] = mode == 2 ? inv_n[i] * inv_batch : 0.0f;
         }
-        dh[(size_t)i * 16 + c] = dz * w;
-        accw = fmaf(dz, hv, accw);
-        accb += dz;
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int i = i0 + u * stride;
+            if (i >= n) break;
+            const float z = row16_sum(hv[u] * w) + b;
+            if (c == 0 && logits) logits[i] = z;
+            if (mode == 0) continue;
+            float dz;
+            if (mode == 1) {
+                dz = yv[u];
+            } else {
+                const float e = expf(-fabsf(z));
+                const float sig = z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                dz = wv[u] * (sig - yv[u]);
+                accl += wv[u] * (fmaxf(z, 0.0f) - z * yv[u] + log1pf(e));
+            }
+            dh[(size_t)i * 16 + c] = dz * w;
+            accw = fmaf(dz, hv[u], accw);
+            accb += dz;
+        }
     }
     if (mode == 0) return;
     sh[grp][c] = accw;

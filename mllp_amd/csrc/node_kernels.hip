@@ -407,54 +407,67 @@ __global__ __launch_bounds__(BLOCK) void head_kernel(int mode, int n, const floa
                                                      float inv_batch, const float* __restrict__ dz_in,
                                                      float* __restrict__ logits, float* __restrict__ dh,
                                                      float* __restrict__ partials) {
-    __shared__ float sh[16][18];
-    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    // A wavefront takes 64 consecutive nodes per round.  Round part 1: sixteen steps, step u reads the 16 channels of nodes
+    // base + 4 u + q (q = the 16-lane group inside the wavefront: 256 contiguous bytes per load) and sums <h, w>; lane (q, c)
+    // keeps the logit of step u = c, i.e. of node base + 4 c + q.  Part 2: every lane does the scalar arithmetic of ITS node
+    // once (sigmoid, loss: with 16 lanes per node all repeating it the kernel was VALU-bound, 0.45 ms for 0.7 GB at 5.12 M
+    // nodes).  Part 3: sixteen steps again, dz of step u comes from lane u of the group (DPP row broadcast), dh = dz w.
+    __shared__ float sh[BLOCK / 64][18];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
     const float w = fcw[c], b = fcb[0];
     float accw = 0.0f, accb = 0.0f, accl = 0.0f;
-    // four nodes per 16-lane group in flight: with one, the 312 dependent load -> store rounds of a group at 5.12 M nodes made
-    // the kernel 0.53 ms for 0.7 GB (latency, not bandwidth)
-    constexpr int HU = 4;
-    const int stride = gridDim.x * 16;
-    for (int i0 = blockIdx.x * 16 + grp; i0 < n; i0 += HU * stride) {
-        float hv[HU], yv[HU], wv[HU];
+    const int per_round = (BLOCK / 64) * 64;
+    for (int base = blockIdx.x * per_round + wave * 64; base < n; base += gridDim.x * per_round) {
+        float hv[16];
 #pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int i = min(i0 + u * stride, n - 1);
-            hv[u] = h[(size_t)i * 16 + c];
-            yv[u] = mode == 1 ? dz_in[i] : mode == 2 ? labels[i] : 0.0f;
-            wv[u] = mode == 2 ? inv_n[i] * inv_batch : 0.0f;
+        for (int u = 0; u < 16; ++u) hv[u] = h[(size_t)min(base + 4 * u + q, n - 1) * 16 + c];
+        float z = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float zu = row16_sum(hv[u] * w) + b;
+            z = c == u ? zu : z;
         }
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int i = i0 + u * stride;
-            if (i >= n) break;
-            const float z = row16_sum(hv[u] * w) + b;
-            if (c == 0 && logits) logits[i] = z;
-            if (mode == 0) continue;
-            float dz;
+        const int node = base + 4 * c + q;
+        const bool ok = node < n;
+        if (ok && logits) logits[node] = z;
+        if (mode == 0) continue;
+        float dz = 0.0f;
+        if (ok) {
             if (mode == 1) {
-                dz = yv[u];
+                dz = dz_in[node];
             } else {
+                const float y = labels[node];
+                const float wn = inv_n[node] * inv_batch;
                 const float e = expf(-fabsf(z));
                 const float sig = z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-                dz = wv[u] * (sig - yv[u]);
-                accl += wv[u] * (fmaxf(z, 0.0f) - z * yv[u] + log1pf(e));
+                dz = wn * (sig - y);
+                accl += wn * (fmaxf(z, 0.0f) - z * y + log1pf(e));
             }
-            dh[(size_t)i * 16 + c] = dz * w;
-            accw = fmaf(dz, hv[u], accw);
-            accb += dz;
+        }
+        accb += dz;
+        float dzu[16];
+        dzu[0] = dpp_mov<0x150>(dz);  dzu[1] = dpp_mov<0x151>(dz);  dzu[2] = dpp_mov<0x152>(dz);  dzu[3] = dpp_mov<0x153>(dz);
+        dzu[4] = dpp_mov<0x154>(dz);  dzu[5] = dpp_mov<0x155>(dz);  dzu[6] = dpp_mov<0x156>(dz);  dzu[7] = dpp_mov<0x157>(dz);
+        dzu[8] = dpp_mov<0x158>(dz);  dzu[9] = dpp_mov<0x159>(dz);  dzu[10] = dpp_mov<0x15A>(dz); dzu[11] = dpp_mov<0x15B>(dz);
+        dzu[12] = dpp_mov<0x15C>(dz); dzu[13] = dpp_mov<0x15D>(dz); dzu[14] = dpp_mov<0x15E>(dz); dzu[15] = dpp_mov<0x15F>(dz);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int nu = base + 4 * u + q;
+            if (nu < n) dh[(size_t)nu * 16 + c] = dzu[u] * w;
+            accw = fmaf(dzu[u], hv[u], accw);
         }
     }
     if (mode == 0) return;
-    sh[grp][c] = accw;
-    if (c == 0) {
-        sh[grp][16] = accb;
-        sh[grp][17] = accl;
-    }
+    // per channel: the four groups of a wavefront, then the wavefronts; db and the loss: all lanes
+    accw += __shfl_xor(accw, 16, 64);
+    accw += __shfl_xor(accw, 32, 64);
+    for (int o = 32; o > 0; o >>= 1) { accb += __shfl_xor(accb, o, 64); accl += __shfl_xor(accl, o, 64); }
+    if (lane < 16) sh[wave][lane] = accw;
+    if (lane == 0) { sh[wave][16] = accb; sh[wave][17] = accl; }
     __syncthreads();
     if (threadIdx.x < 18) {
         float v = 0.0f;
-        for (int gq = 0; gq < 16; ++gq) v += sh[gq][threadIdx.x];
+        for (int gq = 0; gq < BLOCK / 64; ++gq) v += sh[gq][threadIdx.x];
         partials[(size_t)blockIdx.x * 18 + threadIdx.x] = v;
     }
 }
